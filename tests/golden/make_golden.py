@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the REAL reference (oracle/_ref/libzling_ref.so).
+
+Run in the build container only (it needs /root/reference to have been compiled by
+oracle/Makefile):   python tests/golden/make_golden.py
+Writes:
+  <name>.bin / <name>.e<level>.zlng   for tests/corpus.py SMALL (inputs and reference streams)
+  manifest.json                        SHA-256 of every input and of every reference stream,
+                                       stream sizes, per-sub-block (encpos, rlen, olen) lists,
+                                       SHA-256 of the reference ROLZ u16 token stream per block
+  huff_tables.npz                      tie-heavy frequency tables + the reference's code lengths
+The files are data (inputs and expected outputs); no reference source is stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import corpus  # noqa: E402
+from oracle_py import Reference  # noqa: E402
+
+
+def walk(z):
+    """(encpos, rlen, olen) per sub-block, -1 marks a block end."""
+    out, p = [], 0
+    while p < len(z):
+        f = z[p]; p += 1
+        if f == 0:
+            out.append(-1)
+            continue
+        e, r, o = (int.from_bytes(z[p + 4 * k: p + 4 * k + 4].tobytes(), "big") for k in range(3))
+        p += 12 + o
+        out.append([e, r, o])
+    assert p == len(z)
+    return out
+
+
+def main():
+    ref = Reference()
+    man = {"inputs": {}, "streams": {}, "rolz": {}}
+    for name in corpus.ALL:
+        x = corpus.get(name)
+        man["inputs"][name] = {"size": int(x.size), "sha256": corpus.sha(x)}
+        small = name in corpus.SMALL
+        if small:
+            x.tofile(os.path.join(HERE, name + ".bin"))
+        levels = range(5) if (small or name in ("mixed_e4", "text_700k")) else (0, 4)
+        for lv in levels:
+            z = ref.encode(x, lv)
+            rc, back, _ = ref.decode(z, x.size)
+            assert rc == 0 and np.array_equal(back, x), (name, lv)
+            key = "%s.e%d" % (name, lv)
+            man["streams"][key] = {"size": int(z.size), "sha256": corpus.sha(z)}
+            if small:
+                z.tofile(os.path.join(HERE, key + ".zlng"))
+            else:
+                man["streams"][key]["subblocks"] = walk(z)
+        if name in ("text_700k", "rand_1m", "abc_1m", "skew_400k"):
+            for lv in (0, 4):
+                t, cuts = ref.rolz_block(x[: corpus.BLOCK], lv)
+                man["rolz"]["%s.e%d" % (name, lv)] = {"sha256_u16": corpus.sha(t), "cuts": cuts}
+    # Huffman length tables: tie-heavy distributions
+    rng = np.random.Generator(np.random.PCG64(99))
+    freqs, lens, meta = [], [], []
+    for n, limit in ((514, 15), (32, 8)):
+        for k in range(150):
+            kind = k % 6
+            if kind == 0: f = rng.integers(0, 4, n)
+            elif kind == 1: f = rng.integers(0, 2, n) * rng.integers(1, 3, n)
+            elif kind == 2: f = (rng.zipf(1.3, n) % 100000) * (rng.random(n) < 0.7)
+            elif kind == 3: f = np.where(rng.random(n) < 0.3, 1, 0) + (np.arange(n) < 3) * rng.integers(1000, 100000)
+            elif kind == 4: f = (2.0 ** rng.integers(0, 24, n)).astype(np.int64) * (rng.random(n) < 0.5)
+            else: f = rng.integers(0, 262144, n) * (rng.random(n) < 0.2)
+            f = np.asarray(f, dtype=np.uint32)
+            if k == 7: f[:] = 0
+            if k == 8: f[:] = 0; f[n // 2] = 5
+            full = np.zeros(514, np.uint32); full[:n] = f
+            l = np.zeros(514, np.uint32); l[:n] = ref.length_table(f, limit)
+            freqs.append(full); lens.append(l); meta.append((n, limit))
+    np.savez_compressed(os.path.join(HERE, "huff_tables.npz"), freq=np.array(freqs), len=np.array(lens),
+                        meta=np.array(meta))
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, separators=(",", ":"))
+    print("wrote", len(man["inputs"]), "inputs,", len(man["streams"]), "streams")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""Live differential: oracle restatement vs the real reference build (oracle/_ref).
+
+Skipped when oracle/_ref/libzling_ref.so is absent (it is built only where /root/reference
+exists, and travels to the GPU box as a prebuilt file).
+"""
+import numpy as np
+import pytest
+
+from oracle_py import Reference
+
+pytestmark = pytest.mark.skipif(not Reference.available(), reason="oracle/_ref not built")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return Reference()
+
+
+def test_random_inputs_all_levels(oracle, ref):
+    rng = np.random.Generator(np.random.PCG64(2024))
+    from oracle_py import textgen
+    text = textgen(3_000_000, 50)
+    for it in range(40):
+        kind = it % 4
+        n = int(rng.integers(0, 400_000))
+        if kind == 0:
+            x = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:
+            o = int(rng.integers(0, text.size - n))
+            x = text[o:o + n]
+        elif kind == 2:
+            x = rng.integers(0, int(rng.integers(1, 6)), n, dtype=np.uint8)
+        else:
+            o = int(rng.integers(0, text.size - n))
+            x = text[o:o + n].copy()
+            flips = rng.integers(0, max(n, 1), n // 50)
+            x[flips] = rng.integers(0, 256, flips.size, dtype=np.uint8)
+        lv = it % 5
+        a, b = oracle.encode(x, lv), ref.encode(x, lv)
+        assert np.array_equal(a, b), (it, lv, n)
+        rc, back = oracle.decode(b, n)
+        assert rc == 0 and np.array_equal(back, x)
+
+
+def test_length_tables_tie_heavy(oracle, ref):
+    rng = np.random.Generator(np.random.PCG64(7))
+    for it in range(3000):
+        n, limit = ((514, 15), (32, 8))[it & 1]
+        k = it % 7
+        if k == 0: f = rng.integers(0, 3, n)
+        elif k == 1: f = rng.integers(0, 2, n)
+        elif k == 2: f = rng.zipf(1.2, n) % 50000
+        elif k == 3: f = (2 ** rng.integers(0, 20, n)) * (rng.random(n) < 0.4)
+        elif k == 4: f = rng.integers(0, 262144, n) * (rng.random(n) < 0.1)
+        elif k == 5: f = np.full(n, int(rng.integers(1, 9)))
+        else: f = np.maximum(0, rng.normal(3, 3, n)).astype(np.int64)
+        f = np.asarray(f, dtype=np.uint32)
+        assert np.array_equal(oracle.length_table(f, limit), ref.length_table(f, limit)), it
