@@ -1,0 +1,121 @@
+/*
+ * zlng.h -- C-ABI of the MI355X-native ROLZ+Huffman block codec (libzlng_hip.so).
+ *
+ * This is the drop-in boundary for libzling's hot path.  It sits exactly where
+ * the reference's block driver (src/libzling.cpp:187-284 for Encode, :306-420 for
+ * Decode) calls into its private codec classes:
+ *
+ *   reference call site                                   replaced by
+ *   ---------------------------------------------------   --------------------------
+ *   EncodeResource ctor            src/libzling.cpp:108    zlng_create(.., is_encode=1)
+ *   lzencoder->Reset()             src/libzling.cpp:197  \
+ *   lzencoder->Encode(..)          src/libzling.cpp:206   |
+ *   freq loop                      src/libzling.cpp:219   |  zlng_encode_blocks /
+ *   ZlingMakeLengthTable x2        src/libzling.cpp:225   |  zlng_encode_blocks_device
+ *   ZlingMakeEncodeTable x2        src/libzling.cpp:228   |  (a whole range of 16 MiB
+ *   table + bit-pack loops         src/libzling.cpp:232   |   blocks per call)
+ *   level adaptation               src/libzling.cpp:261   |
+ *   sub-block / block framing      src/libzling.cpp:200,269-279 /
+ *   DecodeResource ctor            src/libzling.cpp:136    zlng_create(.., is_encode=0)
+ *   Decode body                    src/libzling.cpp:306-420 zlng_decode_blocks
+ *   ~EncodeResource/~DecodeResource                        zlng_destroy
+ *
+ * The C++ API baidu::zling::{Encode,Decode,Inputter,Outputter,ActionHandler}
+ * (src/libzling.h:44-45, src/libzling_utils.h:48-119) is re-implemented on top of
+ * this ABI in libzling_amd/cxx/ (libzling_amd.so, headers in include/libzling/).
+ *
+ * Plain C types only; no exceptions cross the ABI; one context is used from one
+ * thread at a time; all working memory lives in HBM and belongs to the context.
+ * The stream state that the reference keeps inside its long-lived encoder object --
+ * the 256 MTF tables (src/libzling_lz.h:105; they are NOT reset per block,
+ * src/libzling_lz.cpp:197-209) and `current_level` (src/libzling.cpp:185) --
+ * is carried by the context from one call to the next and can be exported /
+ * imported for block-range sharding across GPUs.
+ */
+#ifndef ZLNG_H
+#define ZLNG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZLNG_BLOCK_SIZE   16777216u   /* kBlockSizeIn, src/libzling.cpp:70 */
+#define ZLNG_MTF_STATE    65536u      /* 256 tables x 256 bytes, src/libzling_lz.h:50-57 */
+
+/* error codes (negative); 0 = success */
+enum {
+    ZLNG_OK            =  0,
+    ZLNG_E_ARG         = -1,   /* bad argument (level outside 0..4, NULL, misaligned range) */
+    ZLNG_E_NOMEM       = -2,   /* HBM / host allocation failed (reference: std::bad_alloc)   */
+    ZLNG_E_CAP         = -3,   /* output capacity too small                                  */
+    ZLNG_E_DEVICE      = -4,   /* HIP runtime error, or no gfx950 device / kernels missing   */
+    ZLNG_E_PAYLOAD     = -5,   /* a sub-block payload exceeds 393,216 B (kBlockSizeHuffman); the
+                                  reference would overrun obuf here, src/libzling.cpp:232-257  */
+    /* decode: one code per reference exception (src/libzling.cpp:316,327,382,392,399,407) */
+    ZLNG_E_FLAG        = -10,  /* "invalid encflag."                         */
+    ZLNG_E_BLOCKSIZE   = -11,  /* "invalid block size."                      */
+    ZLNG_E_CODE1       = -12,  /* "invalid huffman stream. (bad code1)"      */
+    ZLNG_E_CODE2       = -13,  /* "invalid huffman stream. (bad code2)"      */
+    ZLNG_E_EXBITS      = -14,  /* "invalid huffman stream. (bad ex-bits)"    */
+    ZLNG_E_LZ          = -15,  /* "lzdecode failed."                         */
+    ZLNG_E_TRUNC       = -16   /* stream ends inside a sub-block (reference reads garbage) */
+};
+
+typedef struct zlng_ctx zlng_ctx;
+
+/* Number of usable gfx950 devices (0 if none; the library never falls back to the CPU). */
+int zlng_device_count(void);
+
+/* Create a stream context on HIP device `device`.  level 0..4 (ignored for decode).
+ * max_blocks = largest number of 16 MiB blocks a single call will pass (sizes the HBM pools).
+ * Returns NULL on error; *err (optional) receives the code. */
+zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int* err);
+void      zlng_destroy(zlng_ctx*);
+
+/* Worst-case .zlng size for in_len input bytes. */
+size_t zlng_encode_bound(size_t in_len);
+
+/* Encode a range of blocks held in HOST memory.  `in_len` must be a multiple of
+ * ZLNG_BLOCK_SIZE except for the final call of a stream.  Emits the blocks' complete
+ * framing (sub-block headers, payloads, per-block 0x00).  per_block_out_end (optional,
+ * ceil(in_len/16Mi) entries) receives the end offset of each block's bytes inside `out`,
+ * so the C++ shim can push bytes and fire ActionHandler::OnProcess in the reference's order. */
+int zlng_encode_blocks(zlng_ctx*, const uint8_t* in, size_t in_len,
+                       uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+
+/* Same, with input and output already resident in this device's HBM (hipMalloc'd or a
+ * torch tensor's data_ptr()).  d_in must be readable for in_len + 512 bytes. */
+int zlng_encode_blocks_device(zlng_ctx*, const void* d_in, size_t in_len,
+                              void* d_out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+
+/* Split form for block-range sharding: the parse of a range does not depend
+ * on the incoming MTF state, the rank + Huffman stages do.  parse -> (import state) -> finish. */
+int zlng_encode_parse_device(zlng_ctx*, const void* d_in, size_t in_len);
+int zlng_encode_finish_device(zlng_ctx*, void* d_out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+
+/* Stream state hand-off: 65,536 bytes of MTF tables (context-major) + current_level. */
+int zlng_get_state(zlng_ctx*, uint8_t mtf[ZLNG_MTF_STATE], int* current_level);
+int zlng_set_state(zlng_ctx*, const uint8_t mtf[ZLNG_MTF_STATE], int current_level);
+
+/* Decode a stream prefix made of whole blocks from HOST memory; *in_used gets the bytes consumed. */
+int zlng_decode_blocks(zlng_ctx*, const uint8_t* in, size_t in_len, size_t* in_used,
+                       uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+int zlng_decode_blocks_device(zlng_ctx*, const void* d_in, size_t in_len, size_t* in_used,
+                              void* d_out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+
+/* Per-stage device time of the last encode/decode call in milliseconds (HIP events on the
+ * context's stream).  names[i] is a static string; returns the number of stages filled. */
+int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
+
+/* The hipStream_t the context launches on (as void*), for callers that need to order work. */
+void* zlng_stream(zlng_ctx*);
+
+const char* zlng_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZLNG_H */

@@ -1,0 +1,460 @@
+// zlng_api.hip -- the C-ABI of include/zlng.h: context, HBM pools, stage orchestration.
+//
+// Host-side driver of the encode pipeline for a RANGE of 16 MiB blocks per call:
+//   K0 dict reset -> K1 parse (per block) -> K2 rank (per context, stream order)
+//   -> K3 histogram -> K4 lengths/codes (per sub-block) -> K5 layout scan -> K6 pack+frame
+// replacing one iteration range of the reference's outer loop (src/libzling.cpp:187-284).
+// There is no CPU code path: every stage is a gfx950 kernel and every entry point fails with
+// ZLNG_E_DEVICE when no device / kernel image is available.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/zlng.h"
+#include "zlng_common.h"
+#include "zlng_kernels.h"
+
+using namespace zlng;
+
+namespace {
+
+constexpr int kMaxStages = 12;
+
+struct StageTimer {
+    hipEvent_t ev[kMaxStages + 1];
+    const char* name[kMaxStages];
+    int n = 0;
+    bool ok = false;
+};
+
+}  // namespace
+
+struct zlng_ctx {
+    int device = 0;
+    int level = 0;
+    int current_level = 0;        // src/libzling.cpp:185, carried across calls (H3)
+    bool is_encode = true;
+    uint32_t max_blocks = 0;
+    hipStream_t stream = nullptr;
+    hipError_t last_hip_error = hipSuccess;
+
+    // HBM pools (sized for max_blocks)
+    uint8_t*  d_in = nullptr;      size_t in_cap = 0;     // staging for the host-input entry point
+    uint8_t*  d_out = nullptr;     size_t out_cap = 0;    // staging for the host-output entry point
+    uint8_t*  d_dict = nullptr;
+    uint32_t* d_tok = nullptr;
+    SubCut*   d_cuts = nullptr;
+    uint32_t* d_nsub = nullptr;
+    uint32_t* d_ntok = nullptr;
+    uint8_t*  d_sched = nullptr;
+    uint32_t* d_freq = nullptr;
+    uint8_t*  d_lens = nullptr;
+    uint16_t* d_codes = nullptr;
+    uint32_t* d_olen = nullptr;
+    uint64_t* d_sub_off = nullptr;
+    uint64_t* d_blk_end = nullptr;
+    uint64_t* d_summary = nullptr;
+    uint8_t*  d_mtf = nullptr;        // live MTF tables (65,536 B)
+    uint8_t*  d_mtf_saved = nullptr;  // tables at call entry (restored when a level re-run is needed)
+
+    // host mirrors
+    std::vector<uint8_t>  h_sched;
+    std::vector<uint32_t> h_nsub, h_olen;
+    std::vector<SubCut>   h_cuts;
+    std::vector<uint64_t> h_blk_end;
+
+    // state of a parse awaiting its finish (split entry points)
+    const uint8_t* pending_in = nullptr;
+    size_t pending_len = 0;
+    uint32_t pending_blocks = 0;
+
+    StageTimer timer;
+    int parser_kind = 0;              // 0 = wavefront-speculative (default), 1 = serial cross-check form
+};
+
+namespace {
+
+const uint8_t k_mtfinit[256] = {   // src/tables/gen.py:33-48
+     32, 101, 116,  97, 105, 111, 110, 114, 115, 108, 104, 100,  99, 117,  93,  91,
+    109, 112, 103, 102,  10, 121,  98,  39, 119,  46,  44, 118,  59,  38, 124,  47,
+     49, 107,  61,  48,  67,  65,  58,  45,  84,  83,  60,  62,  50, 113,  73,  57,
+     42, 120,  41,  40,  66,  77,  80,  69,  68,  53,  51,  72,  70,  56,  52,  71,
+     82,  54,  76,  55,  78,  87, 122, 125, 123,  79, 106,  85,  74,  75, 208,  95,
+    195,  35,  86, 215,  90,  34,  89, 209, 128, 224, 184, 131,  92, 227,  37,  33,
+    176, 169, 206, 226, 130,  63,  88,  81, 161, 153,  43, 129, 188, 179, 216, 164,
+    181, 189, 148, 190, 173, 187, 186, 229, 225, 167, 217, 177, 178, 168, 149, 185,
+    197, 144, 147, 196, 207, 194, 180, 156, 132, 170, 166, 136, 182, 191,   9, 230,
+    141, 160, 175,  36, 152, 140, 165, 145,  94, 133, 163, 183, 171, 157, 137, 174,
+    134, 135, 236, 151, 231, 155, 201, 158, 138, 143, 150, 162, 159, 139, 172, 154,
+    126, 232, 235, 146, 233, 228, 202, 203, 142, 214, 237, 204, 219, 234, 213,  96,
+    218, 199,  64, 210, 239, 198, 211, 205, 212, 240, 222, 220, 200,   0,   1,   2,
+      3,   4,   5,   6,   7,   8,  11,  12,  13,  14,  15,  16,  17,  18,  19,  20,
+     21,  22,  23,  24,  25,  26,  27,  28,  29,  30,  31, 127, 192, 193, 221, 223,
+    238, 241, 242, 243, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255,
+};
+
+#define CTX_HIP(expr)                                                                      \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->last_hip_error = e_; return ZLNG_E_DEVICE; } } while (0)
+
+template <typename T>
+int dev_alloc(zlng_ctx* c, T** p, size_t count) {
+    void* v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T));
+    if (e != hipSuccess) { c->last_hip_error = e; return e == hipErrorOutOfMemory ? ZLNG_E_NOMEM : ZLNG_E_DEVICE; }
+    *p = static_cast<T*>(v);
+    return ZLNG_OK;
+}
+
+void timer_begin(zlng_ctx* c) {
+    c->timer.n = 0;
+    c->timer.ok = true;
+    hipEventRecord(c->timer.ev[0], c->stream);
+}
+void timer_mark(zlng_ctx* c, const char* name) {
+    if (c->timer.n >= kMaxStages) return;
+    c->timer.name[c->timer.n] = name;
+    c->timer.n++;
+    hipEventRecord(c->timer.ev[c->timer.n], c->stream);
+}
+
+uint32_t blocks_of(size_t n) { return (uint32_t)((n + kBlockIn - 1) / kBlockIn); }
+
+int ensure_in(zlng_ctx* c, size_t bytes) {
+    if (c->in_cap >= bytes) return ZLNG_OK;
+    if (c->d_in) hipFree(c->d_in);
+    c->d_in = nullptr; c->in_cap = 0;
+    int rc = dev_alloc(c, &c->d_in, bytes);
+    if (rc == ZLNG_OK) c->in_cap = bytes;
+    return rc;
+}
+int ensure_out(zlng_ctx* c, size_t bytes) {
+    if (c->out_cap >= bytes) return ZLNG_OK;
+    if (c->d_out) hipFree(c->d_out);
+    c->d_out = nullptr; c->out_cap = 0;
+    int rc = dev_alloc(c, &c->d_out, bytes);
+    if (rc == ZLNG_OK) c->out_cap = bytes;
+    return rc;
+}
+
+void launch_parse(zlng_ctx* c, const ParseArgs& pa, uint32_t nb) {
+    if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
+    else launch_rolz_parse_wave(pa, nb, c->stream);
+}
+
+// Parse + rank + histogram + lengths for nb blocks under the current level schedule; repeats
+// with a corrected schedule when the reference's level adaptation (src/libzling.cpp:261-266)
+// would have chosen differently.  At level 0 the schedule is always right (fallback == level).
+int run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, bool rank_now) {
+    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched};
+    launch_dict_reset(c->d_dict, nb, c->stream);
+    timer_mark(c, "dict_reset");
+    launch_parse(c, pa, nb);
+    timer_mark(c, "rolz_parse");
+    (void)rank_now;
+    return ZLNG_OK;
+}
+
+int run_back(zlng_ctx* c, uint32_t nb, uint8_t* d_out, size_t out_cap) {
+    MtfArgs ma{c->d_tok, c->d_ntok, nb, c->d_mtf};
+    launch_mtf_rank(ma, c->stream);
+    timer_mark(c, "mtf_rank");
+    HuffArgs ha{c->d_tok, c->d_cuts, c->d_nsub, nb, c->d_freq, c->d_lens, c->d_codes, c->d_olen,
+                c->d_sub_off, c->d_blk_end, c->d_summary, d_out, (uint64_t)out_cap};
+    launch_histogram(ha, c->stream);
+    timer_mark(c, "histogram");
+    launch_lengths(ha, c->stream);
+    timer_mark(c, "huff_lengths");
+    return ZLNG_OK;
+}
+
+// Host check of the level schedule against what the reference would have used.  Returns true
+// if consistent; otherwise rewrites h_sched from the first disagreement on (propagating the
+// corrected level forward as the new speculation).  *final_level gets current_level after the range.
+bool verify_schedule(zlng_ctx* c, uint32_t nb, int entry_level, int* final_level) {
+    int cur = entry_level;
+    for (uint32_t b = 0; b < nb; b++) {
+        uint32_t old = 0;
+        for (uint32_t s = 0; s < c->h_nsub[b] && s < (uint32_t)kMaxSub; s++) {
+            const size_t si = (size_t)b * kMaxSub + s;
+            if (c->h_sched[si] != (uint8_t)cur) {
+                const size_t total = (size_t)nb * kMaxSub;
+                for (size_t k = si; k < total; k++) c->h_sched[k] = (uint8_t)cur;
+                return false;
+            }
+            const uint32_t enc = c->h_cuts[si].encpos;
+            const double ratio = 1.0 * (double)c->h_olen[si] / (double)(enc - old + 1);
+            cur = ratio > 0.95 ? 0 : c->level;
+            old = enc;
+        }
+    }
+    *final_level = cur;
+    return true;
+}
+
+int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t* d_out, size_t out_cap,
+                       size_t* out_len, size_t* per_block_out_end, bool do_parse) {
+    if (!c || !c->is_encode || !out_len) return ZLNG_E_ARG;
+    *out_len = 0;
+    if (in_len == 0) return ZLNG_OK;
+    if (!d_in || !d_out || ((uintptr_t)d_out & 3)) return ZLNG_E_ARG;
+    const uint32_t nb = blocks_of(in_len);
+    if (nb > c->max_blocks) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+
+    const int entry_level = c->current_level;
+    const size_t nsubs = (size_t)nb * kMaxSub;
+    if (do_parse) {
+        timer_begin(c);
+        for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)(k == 0 ? entry_level : c->level);
+        // the entry level only differs from `level` when the previous range ended incompressible
+        if (entry_level != c->level) for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)entry_level;
+    }
+    CTX_HIP(hipMemcpyAsync(c->d_mtf_saved, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+
+    int final_level = entry_level;
+    for (int attempt = 0;; attempt++) {
+        if (do_parse || attempt > 0) {
+            CTX_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
+            run_front(c, d_in, in_len, nb, true);
+        }
+        if (attempt > 0) CTX_HIP(hipMemcpyAsync(c->d_mtf, c->d_mtf_saved, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+        run_back(c, nb, d_out, out_cap);
+        if (c->level == 0) { final_level = 0; break; }        // level 0: adaptation is inert
+        CTX_HIP(hipMemcpyAsync(c->h_nsub.data(), c->d_nsub, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        CTX_HIP(hipMemcpyAsync(c->h_cuts.data(), c->d_cuts, nsubs * sizeof(SubCut), hipMemcpyDeviceToHost, c->stream));
+        CTX_HIP(hipMemcpyAsync(c->h_olen.data(), c->d_olen, nsubs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        CTX_HIP(hipStreamSynchronize(c->stream));
+        if (verify_schedule(c, nb, entry_level, &final_level)) break;
+        if (attempt > 4 * kMaxSub * (int)nb) return ZLNG_E_DEVICE;   // cannot happen: each pass fixes >= 1 sub-block
+    }
+
+    HuffArgs ha{c->d_tok, c->d_cuts, c->d_nsub, nb, c->d_freq, c->d_lens, c->d_codes, c->d_olen,
+                c->d_sub_off, c->d_blk_end, c->d_summary, d_out, (uint64_t)out_cap};
+    launch_layout(ha, c->stream);
+    timer_mark(c, "layout_scan");
+    launch_pack(ha, c->stream);
+    timer_mark(c, "huff_pack");
+
+    uint64_t summary[2] = {0, 0};
+    CTX_HIP(hipMemcpyAsync(summary, c->d_summary, sizeof summary, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipMemcpyAsync(c->h_blk_end.data(), c->d_blk_end, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    CTX_HIP(hipGetLastError());
+    if (summary[1] & 2) return ZLNG_E_DEVICE;
+    if (summary[1] & 1) return ZLNG_E_PAYLOAD;
+    if (summary[1] & 4) return ZLNG_E_CAP;
+    *out_len = (size_t)summary[0];
+    if (per_block_out_end) for (uint32_t b = 0; b < nb; b++) per_block_out_end[b] = (size_t)c->h_blk_end[b];
+    c->current_level = final_level;
+    return ZLNG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zlng_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int* err) {
+    int dummy;
+    if (!err) err = &dummy;
+    *err = ZLNG_OK;
+    if (level < 0 || level > 4 || max_blocks <= 0 || max_blocks > 8192) { *err = ZLNG_E_ARG; return nullptr; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { *err = ZLNG_E_DEVICE; return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        *err = ZLNG_E_DEVICE;      // kernels are built for gfx950 only; there is no other path
+        return nullptr;
+    }
+    zlng_ctx* c = new (std::nothrow) zlng_ctx();
+    if (!c) { *err = ZLNG_E_NOMEM; return nullptr; }
+    c->device = device;
+    c->level = level;
+    c->current_level = level;
+    c->is_encode = is_encode != 0;
+    c->max_blocks = (uint32_t)max_blocks;
+    const char* pk = getenv("ZLNG_PARSER");
+    c->parser_kind = (pk && strcmp(pk, "serial") == 0) ? 1 : 0;
+    int rc = ZLNG_OK;
+    auto fail = [&](int code) { *err = code; zlng_destroy(c); return (zlng_ctx*)nullptr; };
+    if (hipSetDevice(device) != hipSuccess) return fail(ZLNG_E_DEVICE);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(ZLNG_E_DEVICE);
+    for (int i = 0; i <= kMaxStages; i++) if (hipEventCreate(&c->timer.ev[i]) != hipSuccess) return fail(ZLNG_E_DEVICE);
+    const size_t nb = (size_t)max_blocks, nsubs = nb * kMaxSub;
+    if ((rc = dev_alloc(c, &c->d_mtf, ZLNG_MTF_STATE)) || (rc = dev_alloc(c, &c->d_mtf_saved, ZLNG_MTF_STATE))) return fail(rc);
+    if (c->is_encode) {
+        if ((rc = dev_alloc(c, &c->d_dict, nb * kDictBytes)) || (rc = dev_alloc(c, &c->d_tok, nb * kTokCap)) ||
+            (rc = dev_alloc(c, &c->d_cuts, nsubs)) || (rc = dev_alloc(c, &c->d_nsub, nb)) ||
+            (rc = dev_alloc(c, &c->d_ntok, nb)) || (rc = dev_alloc(c, &c->d_sched, nsubs)) ||
+            (rc = dev_alloc(c, &c->d_freq, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_lens, nsubs * kNsymAll)) ||
+            (rc = dev_alloc(c, &c->d_codes, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_olen, nsubs)) ||
+            (rc = dev_alloc(c, &c->d_sub_off, nsubs)) || (rc = dev_alloc(c, &c->d_blk_end, nb)) ||
+            (rc = dev_alloc(c, &c->d_summary, 4)))
+            return fail(rc);
+        c->h_sched.resize(nsubs);
+        c->h_nsub.resize(nb);
+        c->h_olen.resize(nsubs);
+        c->h_cuts.resize(nsubs);
+        c->h_blk_end.resize(nb);
+    }
+    uint8_t init[ZLNG_MTF_STATE];
+    for (int ctx = 0; ctx < 256; ctx++) memcpy(init + 256 * ctx, k_mtfinit, 256);   // src/libzling_lz.cpp:106-111
+    if (hipMemcpy(c->d_mtf, init, ZLNG_MTF_STATE, hipMemcpyHostToDevice) != hipSuccess) return fail(ZLNG_E_DEVICE);
+    return c;
+}
+
+void zlng_destroy(zlng_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
+                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+size_t zlng_encode_bound(size_t n) {
+    // every u16 entry covers >= 1 input byte and costs <= 2 payload bytes; every sub-block but the
+    // last of a block has >= 262143 entries
+    const size_t nblk = (n + kBlockIn - 1) / kBlockIn;
+    const size_t nsub = n / 262143 + nblk + 1;
+    return nsub * (kHeaderBytes + kTableBytes + 8) + 2 * n + nblk + 64;
+}
+
+int zlng_encode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, void* d_out, size_t out_cap,
+                              size_t* out_len, size_t* per_block_out_end) {
+    return encode_device_impl(c, static_cast<const uint8_t*>(d_in), in_len, static_cast<uint8_t*>(d_out), out_cap,
+                              out_len, per_block_out_end, true);
+}
+
+int zlng_encode_blocks(zlng_ctx* c, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, size_t* out_len,
+                       size_t* per_block_out_end) {
+    if (!c || !c->is_encode || !out_len) return ZLNG_E_ARG;
+    *out_len = 0;
+    if (in_len == 0) return ZLNG_OK;
+    if (!in || !out) return ZLNG_E_ARG;
+    if (blocks_of(in_len) > c->max_blocks) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    int rc;
+    const size_t bound = zlng_encode_bound(in_len);
+    if ((rc = ensure_in(c, in_len + 512)) || (rc = ensure_out(c, bound))) return rc;
+    CTX_HIP(hipMemcpyAsync(c->d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+    CTX_HIP(hipMemsetAsync(c->d_in + in_len, 0, 512, c->stream));
+    size_t produced = 0;
+    rc = encode_device_impl(c, c->d_in, in_len, c->d_out, bound, &produced, per_block_out_end, true);
+    if (rc != ZLNG_OK) return rc;
+    if (produced > out_cap) return ZLNG_E_CAP;
+    CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    *out_len = produced;
+    return ZLNG_OK;
+}
+
+int zlng_encode_parse_device(zlng_ctx* c, const void* d_in, size_t in_len) {
+    if (!c || !c->is_encode || !d_in || in_len == 0) return ZLNG_E_ARG;
+    const uint32_t nb = blocks_of(in_len);
+    if (nb > c->max_blocks) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    const size_t nsubs = (size_t)nb * kMaxSub;
+    timer_begin(c);
+    // speculate the requested level everywhere; finish() re-parses if the incoming level disagrees
+    for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)c->level;
+    CTX_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
+    run_front(c, static_cast<const uint8_t*>(d_in), in_len, nb, false);
+    c->pending_in = static_cast<const uint8_t*>(d_in);
+    c->pending_len = in_len;
+    c->pending_blocks = nb;
+    return ZLNG_OK;
+}
+
+int zlng_encode_finish_device(zlng_ctx* c, void* d_out, size_t out_cap, size_t* out_len, size_t* per_block_out_end) {
+    if (!c || !c->pending_in) return ZLNG_E_ARG;
+    const uint8_t* in = c->pending_in;
+    const size_t n = c->pending_len;
+    c->pending_in = nullptr;
+    // a parse speculated at `level` is reusable iff the stream enters this range at `level`
+    const bool reuse = (c->current_level == c->level);
+    return encode_device_impl(c, in, n, static_cast<uint8_t*>(d_out), out_cap, out_len, per_block_out_end, !reuse);
+}
+
+int zlng_get_state(zlng_ctx* c, uint8_t mtf[ZLNG_MTF_STATE], int* current_level) {
+    if (!c || !mtf) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    CTX_HIP(hipMemcpyAsync(mtf, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    if (current_level) *current_level = c->current_level;
+    return ZLNG_OK;
+}
+
+int zlng_set_state(zlng_ctx* c, const uint8_t mtf[ZLNG_MTF_STATE], int current_level) {
+    if (!c || !mtf || current_level < 0 || current_level > 4) return ZLNG_E_ARG;
+    for (int ctx = 0; ctx < 256; ctx++) {           // every table must be a permutation of 0..255
+        bool seen[256] = {false};
+        for (int i = 0; i < 256; i++) { uint8_t v = mtf[256 * ctx + i]; if (seen[v]) return ZLNG_E_ARG; seen[v] = true; }
+    }
+    CTX_HIP(hipSetDevice(c->device));
+    CTX_HIP(hipMemcpyAsync(c->d_mtf, mtf, ZLNG_MTF_STATE, hipMemcpyHostToDevice, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    c->current_level = current_level;
+    return ZLNG_OK;
+}
+
+int zlng_decode_blocks(zlng_ctx*, const uint8_t*, size_t, size_t*, uint8_t*, size_t, size_t*, size_t*) {
+    return ZLNG_E_DEVICE;   // decode kernels: see decode.hip (not linked in this build)
+}
+int zlng_decode_blocks_device(zlng_ctx*, const void*, size_t, size_t*, void*, size_t, size_t*, size_t*) {
+    return ZLNG_E_DEVICE;
+}
+
+int zlng_last_timings(zlng_ctx* c, const char** names, float* ms, int cap) {
+    if (!c || !c->timer.ok) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    int n = c->timer.n < cap ? c->timer.n : cap;
+    for (int i = 0; i < n; i++) {
+        names[i] = c->timer.name[i];
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->timer.ev[i], c->timer.ev[i + 1]) != hipSuccess) t = -1.f;
+        ms[i] = t;
+    }
+    return n;
+}
+
+void* zlng_stream(zlng_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+const char* zlng_strerror(int code) {
+    switch (code) {
+        case ZLNG_OK: return "ok";
+        case ZLNG_E_ARG: return "invalid argument";
+        case ZLNG_E_NOMEM: return "out of memory";
+        case ZLNG_E_CAP: return "output capacity too small";
+        case ZLNG_E_DEVICE: return "HIP device error or no gfx950 device";
+        case ZLNG_E_PAYLOAD: return "sub-block payload exceeds 393216 bytes";
+        case ZLNG_E_FLAG: return "baidu::zling::Decode(): invalid encflag.";
+        case ZLNG_E_BLOCKSIZE: return "baidu::zling::Decode(): invalid block size.";
+        case ZLNG_E_CODE1: return "baidu::zling::Decode(): invalid huffman stream. (bad code1)";
+        case ZLNG_E_CODE2: return "baidu::zling::Decode(): invalid huffman stream. (bad code2)";
+        case ZLNG_E_EXBITS: return "baidu::zling::Decode(): invalid huffman stream. (bad ex-bits)";
+        case ZLNG_E_LZ: return "baidu::zling::Decode(): lzdecode failed.";
+        case ZLNG_E_TRUNC: return "truncated stream";
+        default: return "unknown error";
+    }
+}
+
+}  // extern "C"
