@@ -74,33 +74,40 @@ __device__ __forceinline__ bool lazy_probe(uint8_t* dict, const uint8_t* buf, in
     return false;
 }
 
-// MatchAndUpdate, src/libzling_lz.cpp:211-289 (insert first, then walk <= depth chain nodes)
-__device__ __forceinline__ bool match_and_update(uint8_t* dict, uint16_t* heads, const uint8_t* buf, int pos,
-                                                 const LevelCfg cfg, int& match_idx, int& match_len) {
+// MatchAndUpdate, src/libzling_lz.cpp:211-289 (insert first, then walk <= depth chain nodes).
+// `head` is the ring slot this insert takes (the caller owns the per-context head counters).
+// Safe to run wave-uniformly: every lane computes the same thing, lane 0 alone stores.
+__device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, int pos, const LevelCfg cfg,
+                                            uint32_t head, bool writer, int& match_idx, int& match_len) {
     uint32_t h = hash4(buf + pos);
     uint32_t chk = (h / kHashSlots) & 255u;
     uint32_t hc = h % kHashSlots;
     uint32_t ctx = buf[pos - 1];
     Bucket B(dict, ctx);
     uint32_t node = B.hash[hc];
-    uint32_t head = (heads[ctx] + 1u) & (kRing - 1);
-    heads[ctx] = (uint16_t)head;
-    B.suffix[head] = (uint16_t)node;
-    B.offset[head] = (uint32_t)pos | chk << 24;
-    B.hash[hc] = (uint16_t)head;
+    if (writer) {
+        B.suffix[head] = (uint16_t)node;
+        B.offset[head] = (uint32_t)pos | chk << 24;
+        B.hash[hc] = (uint16_t)head;
+    }
     if (node == 65535 || node == head) return false;
 
     int maxlen = kMatchMin - 1;
     uint32_t maxnode = 0;
     for (int i = 0; i < cfg.depth; i++) {
-        uint32_t ov = B.offset[node];
+        // the slot just written is read back as written (it is `head`, checked above for i == 0;
+        // later hits on it end the chain through the position test exactly as in the reference)
+        uint32_t ov = node == head ? ((uint32_t)pos | chk << 24) : B.offset[node];
         uint32_t off = ov & 0xFFFFFF;
         if ((ov >> 24) == chk && buf[pos + maxlen] == buf[off + maxlen]) {
             int len = common_len(buf + pos, buf + off);
             if (len > maxlen) { maxnode = node; maxlen = len; if (maxlen == kMatchMax) break; }
         }
-        node = B.suffix[node];
-        if (node == 65535 || off <= (B.offset[node] & 0xFFFFFF)) break;
+        uint32_t nx = B.suffix[node];
+        if (nx == 65535) break;
+        uint32_t noff = nx == head ? (uint32_t)pos : (B.offset[nx] & 0xFFFFFF);
+        if (off <= noff) break;
+        node = nx;
     }
     if (maxlen < kMatchMin) return false;
     if (maxlen < kLazyLimit) {
@@ -143,7 +150,14 @@ __global__ __launch_bounds__(64) void k_rolz_parse_serial(ParseArgs a) {
         if (ipos == 1 && ipos < ilen) { tok[nt++] = buf[ipos++] | kTokRawCtx << 16; opos++; }
         while (opos + 1 < kSubSyms && ipos < ilen) {
             int midx, mlen;
-            if (ipos + kSentinel < ilen && match_and_update(dict, heads, buf, ipos, cfg, midx, mlen)) {
+            bool hit = false;
+            if (ipos + kSentinel < ilen) {
+                const uint32_t c = buf[ipos - 1];
+                const uint32_t head = (heads[c] + 1u) & (kRing - 1);
+                heads[c] = (uint16_t)head;
+                hit = match_exact(dict, buf, ipos, cfg, head, true, midx, mlen);
+            }
+            if (hit) {
                 tok[nt++] = (uint32_t)(258 + mlen - kMatchMin) | (uint32_t)midx << 16;
                 opos += 2;
                 ipos += mlen;
@@ -178,8 +192,334 @@ void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t 
     hipLaunchKernelGGL(k_rolz_parse_serial, dim3(nblocks), dim3(64), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------ K1 (wavefront form)
+// The production parser.  One wavefront owns a block and advances in rounds over a window of 64
+// consecutive input positions starting at the next token start P:
+//
+//  phase 1  (64 lanes, read-only) lane l evaluates position P+l AS IF it were a token start
+//           against the dictionary state at the start of the round: hash head, the <= depth chain
+//           nodes, the longest-match search and the lazy probes at P+l+1 / P+l+2.  All the
+//           dependent HBM round trips of a token are paid once per window instead of once per token,
+//           and independent loads (ring offset + suffix of a node, the lazy probes' hash heads,
+//           16-byte compare chunks) are issued together to shorten the chain.
+//  phase 2  (wave-uniform walk, mostly SALU) the true token chain inside the window is resolved
+//           serially: P -> P+len -> ...  Each accepted start performs the dictionary insert.  A
+//           lane's speculative result is used only if nothing it READ was written by an earlier
+//           accepted start of the same round:
+//             - its hash slot (ctx, hash13)        -> (keymask & accepted) != 0
+//             - a ring slot it visited: slots are handed out consecutively per context, so only a
+//               visited node within 64 slots ahead of the round's starting head can be hit; such
+//               lanes (rare) are flagged `ring risk` and always take the exact path
+//           (the lazy probes have their own read sets, checked against accepted starts INCLUDING
+//           the lane's own insert -- a probe may hit the entry just inserted, src/libzling_lz.cpp:271).
+//           Otherwise the token is re-evaluated by match_exact() against the now-current state,
+//           so the result is the reference's in every case.
+//
+// A single wavefront issues about one instruction per 4 cycles, so the serial walk is written to
+// be short: per-lane facts are packed into a few words that the walk pulls with v_readlane and
+// tests with scalar mask arithmetic.  Same-key / same-context lane sets come from two LDS bitmask
+// tables (64-bit LDS atomic OR, one bit per lane); the word MRU (1 KiB) and the per-context ring
+// heads live in LDS; tokens are staged in a VGPR and stored 64 at a time.
+constexpr int kKeyTab = 4096;                        // 64-bit lane masks, indexed by a hash of (ctx, hash13)
+
+__device__ __forceinline__ uint32_t key_ix(uint32_t ctx, uint32_t hc) { return (hc ^ (ctx * 0x9E5u)) & (kKeyTab - 1); }
+__device__ __forceinline__ uint32_t ring_dist(uint32_t node, uint32_t head0) { return (node - head0 - 1u) & (kRing - 1); }
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ uint32_t hash_of(uint32_t w) { return w + ((w >> 16) & 0xFF) * 137u + (w >> 24) * 13337u; }
+
+// packed speculative result of one lane
+constexpr uint32_t kSpLenMask = 0x1FF;               // bits 0..8  maxlen (3 = none)
+constexpr int      kSpNodeShift = 9;                 // bits 9..20 maxnode
+constexpr uint32_t kSpVeto1 = 1u << 21, kSpVeto2 = 1u << 22, kSpCanMatch = 1u << 23;
+constexpr uint32_t kSpRisk = 1u << 24, kSpRisk1 = 1u << 25, kSpRisk2 = 1u << 26;   // read set near the ring head
+constexpr uint32_t kRiskDist = 64;                   // a round hands out < 64 slots per context
+
+struct Quad { uint32_t a, b, c, d; };
+__device__ __forceinline__ Quad ld128u(const uint8_t* p) { Quad q; __builtin_memcpy(&q, p, 16); return q; }
+
+// byte-wise common prefix of a and b, capped at 259, given that it is going to be compared with
+// a threshold >= 3: returns 0 when the first four bytes differ (GetCommonLength, src/libzling_lz.cpp:66-89).
+__device__ __forceinline__ int common_len_q(const uint8_t* a, const uint8_t* b, const Quad qa) {
+    const Quad qb = ld128u(b);
+    uint32_t x = qa.a ^ qb.a;
+    if (x) return 0;
+    x = qa.b ^ qb.b; if (x) return 4 + (__ffs((int)x) - 1) / 8;
+    x = qa.c ^ qb.c; if (x) return 8 + (__ffs((int)x) - 1) / 8;
+    x = qa.d ^ qb.d; if (x) return 12 + (__ffs((int)x) - 1) / 8;
+    int n = 16;
+    while (n + 4 <= kMatchMax) {
+        x = ld32u(a + n) ^ ld32u(b + n);
+        if (x) return n + (__ffs((int)x) - 1) / 8;
+        n += 4;
+    }
+    while (n < kMatchMax && a[n] == b[n]) n++;
+    return n;
+}
+
+__global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
+    __shared__ uint16_t heads[256];
+    __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
+    __shared__ unsigned long long keytab[kKeyTab];
+    __shared__ unsigned long long ctxtab[256];
+    const uint32_t blk = blockIdx.x;
+    const size_t base = (size_t)blk * kBlockIn;
+    if (base >= a.in_len) return;
+    const uint8_t* buf = a.in + base;
+    const int ilen = (int)((a.in_len - base) < (size_t)kBlockIn ? (a.in_len - base) : (size_t)kBlockIn);
+    uint8_t* dict = a.dict + (size_t)blk * kDictBytes;
+    uint32_t* tok = a.tok + (size_t)blk * kTokCap;
+    SubCut* cuts = a.cuts + (size_t)blk * kMaxSub;
+    const int lane = threadIdx.x;
+    const unsigned long long lane_bit = 1ull << lane;
+
+    for (int i = lane; i < 256; i += 64) { heads[i] = 0; ctxtab[i] = 0; }
+    for (int i = lane; i < kKeyTab; i += 64) keytab[i] = 0;
+    __syncthreads();
+
+    uint32_t tokv = 0, nt = 0;
+    int q = 0, nsub = 0;
+    unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_lredo = 0, n_cand = 0;
+    const bool prof = a.dbg != nullptr;
+    auto emit = [&](uint32_t v) {
+        tokv = lane == (int)(nt & 63) ? v : tokv;
+        nt++;
+        if ((nt & 63) == 0) tok[nt - 64 + lane] = tokv;
+    };
+
+    while (q < ilen) {                               // ---- one sub-block (one EncodeImpl call)
+        const LevelCfg cfg = level_cfg(a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)]);
+        const uint32_t tok_begin = nt;
+        int opos = 0;
+        bool pend = false;                           // match-end MRU update waiting for next round's bytes
+        for (int i = lane; i < 256; i += 64) mru[i] = 0;
+        __syncthreads();
+        if (q == 0) {                                // src/libzling_lz.cpp:150-151
+            emit((uint32_t)buf[0] | kTokRawCtx << 16); q = 1; opos = 1;
+            if (ilen > 1) { emit((uint32_t)buf[1] | kTokRawCtx << 16); q = 2; opos = 2; }
+        }
+
+        while (q < ilen && opos + 1 < kSubSyms) {    // ---- one round
+            const int P = q;
+            unsigned long long t0 = 0, t1 = 0, t2 = 0;
+            if (prof) t0 = __builtin_readcyclecounter();
+            // ---------------- phase 1: speculative evaluation of position P + lane
+            const int pos = P + lane;
+            const bool canm = pos + kSentinel < ilen;
+            uint32_t wp, w4 = 0;
+            if (pos >= 4) wp = ld32u(buf + pos - 4); else wp = ld32u(buf) << (8 * (4 - pos));
+            if (pos < ilen) w4 = ld32u(buf + pos);
+            const uint32_t ctx = wp >> 24;
+            const uint32_t h = hash_of(w4);
+            const uint32_t hc = h % kHashSlots, chk = (h / kHashSlots) & 255u;
+            const uint32_t kix = key_ix(ctx, hc);
+            uint32_t sp = kMatchMin - 1, node0 = 65535, head0 = 0;
+            uint32_t lkix1 = 0, lkix2 = 0, lctx1 = 0, lctx2 = 0;
+            bool lz1 = false, lz2 = false;
+            if (canm) {
+                sp |= kSpCanMatch;
+                atomicOr(&keytab[kix], lane_bit);
+                atomicOr(&ctxtab[ctx], lane_bit);
+                head0 = heads[ctx];
+                const Quad qa = ld128u(buf + pos);               // bytes pos .. pos+15 (pos+275 < ilen)
+                // lazy keys are pure functions of the input: start their chains together with the main one
+                const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
+                lctx1 = w4 & 0xFF; lctx2 = (w4 >> 8) & 0xFF;
+                const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+                const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
+                lkix1 = key_ix(lctx1, hh1); lkix2 = key_ix(lctx2, hh2);
+                Bucket B(dict, ctx), B1(dict, lctx1), B2(dict, lctx2);
+                const uint32_t lhead1 = heads[lctx1], lhead2 = heads[lctx2];
+                node0 = B.hash[hc];
+                uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
+                uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
+                // second hop of all three chains
+                uint32_t ov = B.offset[node0 & (kRing - 1)];
+                uint32_t nx = B.suffix[node0 & (kRing - 1)];
+                uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
+
+                int maxlen = kMatchMin - 1;
+                uint32_t maxnode = 0, node = node0, dmin = kRing - 1;
+                if (node != 65535) {
+                    for (int i = 0; i < cfg.depth; i++) {
+                        dmin = min(dmin, ring_dist(node, head0));
+                        const uint32_t off = ov & 0xFFFFFF;
+                        // next hop's ring entry is fetched together with this hop's compare bytes
+                        const uint32_t nov = B.offset[nx & (kRing - 1)];
+                        const uint32_t nnx = B.suffix[nx & (kRing - 1)];
+                        if ((ov >> 24) == chk) {
+                            const int len = common_len_q(buf + pos, buf + off, qa);
+                            if (len > maxlen) { maxnode = node; maxlen = len; if (maxlen == kMatchMax) break; }
+                        }
+                        if (nx == 65535) break;
+                        dmin = min(dmin, ring_dist(nx, head0));
+                        if (off <= (nov & 0xFFFFFF)) break;
+                        node = nx; ov = nov; nx = nnx;
+                    }
+                }
+                if (dmin < kRiskDist) sp |= kSpRisk;
+                sp = (sp & ~kSpLenMask) | (uint32_t)maxlen | maxnode << kSpNodeShift;
+                if (maxlen >= kMatchMin && maxlen < kLazyLimit) {
+                    const int m = maxlen - 3;
+                    if (want1) {                                 // MatchLazy(pos + 1), src/libzling_lz.cpp:291-316
+                        lz1 = true;
+                        uint32_t ld = kRing - 1, n1 = ln1;
+                        if (n1 != 65535) {
+                            const uint32_t probe = ld32u(buf + pos + 1 + m);
+                            for (int i = 0; i < cfg.lazy1; i++) {
+                                ld = min(ld, ring_dist(n1, lhead1));
+                                const uint32_t off = lov1 & 0xFFFFFF;
+                                if (probe == ld32u(buf + off + m)) { sp |= kSpVeto1; break; }
+                                n1 = B1.suffix[n1];
+                                if (n1 == 65535) break;
+                                ld = min(ld, ring_dist(n1, lhead1));
+                                lov1 = B1.offset[n1];
+                                if (off <= (lov1 & 0xFFFFFF)) break;
+                            }
+                        }
+                        if (ld < kRiskDist) sp |= kSpRisk1;
+                    }
+                    if (want2) {                                 // MatchLazy(pos + 2)
+                        lz2 = true;
+                        uint32_t ld = kRing - 1, n2 = ln2;
+                        if (n2 != 65535) {
+                            const uint32_t probe = ld32u(buf + pos + 2 + m);
+                            for (int i = 0; i < cfg.lazy2; i++) {
+                                ld = min(ld, ring_dist(n2, lhead2));
+                                const uint32_t off = lov2 & 0xFFFFFF;
+                                if (probe == ld32u(buf + off + m)) { sp |= kSpVeto2; break; }
+                                n2 = B2.suffix[n2];
+                                if (n2 == 65535) break;
+                                ld = min(ld, ring_dist(n2, lhead2));
+                                lov2 = B2.offset[n2];
+                                if (off <= (lov2 & 0xFFFFFF)) break;
+                            }
+                        }
+                        if (ld < kRiskDist) sp |= kSpRisk2;
+                    }
+                }
+            }
+            if (prof) t1 = __builtin_readcyclecounter();
+            __syncthreads();                         // all lane bits are in the tables
+            unsigned long long keymask = 0, ctxmask = 0, lkey1 = 0, lkey2 = 0;
+            if (canm) { keymask = keytab[kix]; ctxmask = ctxtab[ctx]; }
+            // a lazy probe is invalidated by an accepted insert with its key, or -- if it walked near the
+            // ring head -- by any accepted insert into its bucket
+            if (lz1) lkey1 = keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
+            if (lz2) lkey2 = keytab[lkix2] | ((sp & kSpRisk2) ? ctxtab[lctx2] : 0ull);
+            __syncthreads();
+            if (canm) { keytab[kix] = 0; ctxtab[ctx] = 0; }
+            const uint32_t km_lo = (uint32_t)keymask, km_hi = (uint32_t)(keymask >> 32);
+            const uint32_t cm_lo = (uint32_t)ctxmask, cm_hi = (uint32_t)(ctxmask >> 32);
+            const uint32_t l1_lo = (uint32_t)lkey1, l1_hi = (uint32_t)(lkey1 >> 32);
+            const uint32_t l2_lo = (uint32_t)lkey2, l2_hi = (uint32_t)(lkey2 >> 32);
+            // MRU operands of this position: as a token start (check key / literal event) and as a match end
+            const uint32_t b_m3 = (wp >> 8) & 0xFF, b_m2 = (wp >> 16) & 0xFF, b_m1 = wp >> 24, b_0 = w4 & 0xFF, b_1 = (w4 >> 8) & 0xFF;
+            const uint32_t x_chk = b_m1 | (b_0 << 8 | b_1) << 16;           // mru[b-1] vs word (b0, b1)
+            const uint32_t x_lit = b_m2 | (b_m1 << 8 | b_0) << 16;          // literal: mru[b-2] <- (b-1, b0)
+            const uint32_t x_end = b_m3 | (b_m2 << 8 | b_m1) << 16;         // match ending here: mru[b-3] <- (b-2, b-1)
+
+            // ---------------- phase 2: resolve the token chain inside [P, P + 64)
+            if (prof) { t2 = __builtin_readcyclecounter(); c_p1 += t1 - t0; c_mask += t2 - t1; n_round++; }
+            unsigned long long acc = 0;              // lanes whose position was an inserting token start
+            if (pend) {                              // match ended beyond the previous window
+                const uint32_t xe = rl(x_end, 0);
+                const uint32_t cu = xe & 0xFF, w = xe >> 16, m = mru[cu];
+                if ((m & 0xFFFF) != w) mru[cu] = (m << 16) | w;
+                pend = false;
+            }
+            while (q < P + 64 && q < ilen && opos + 1 < kSubSyms) {
+                const int sl = q - P;
+                const uint32_t spq = rl(sp, sl);
+                bool is_match = false;
+                int mlen = 0, midx = 0;
+                if (spq & kSpCanMatch) {
+                    const unsigned long long kmq = (unsigned long long)rl(km_hi, sl) << 32 | rl(km_lo, sl);
+                    const unsigned long long cmq = (unsigned long long)rl(cm_hi, sl) << 32 | rl(cm_lo, sl);
+                    const uint32_t head = (rl(head0, sl) + (uint32_t)__popcll(cmq & acc) + 1u) & (kRing - 1);
+                    const bool dirty = (spq & kSpRisk) || (kmq & acc);
+                    acc |= 1ull << sl;
+                    if (prof) { n_cand++; if (dirty) n_redo++; }
+                    if (dirty) {
+                        int mi = 0, ml = 0;
+                        const bool hit = match_exact(dict, buf, q, cfg, head, lane == 0, mi, ml);
+                        is_match = __builtin_amdgcn_readfirstlane((int)hit) != 0;
+                        mlen = __builtin_amdgcn_readfirstlane(ml);
+                        midx = __builtin_amdgcn_readfirstlane(mi);
+                    } else {
+                        if (lane == sl) {            // the insert (src/libzling_lz.cpp:227-230)
+                            Bucket B(dict, ctx);
+                            B.suffix[head] = (uint16_t)node0;
+                            B.offset[head] = (uint32_t)pos | chk << 24;
+                            B.hash[hc] = (uint16_t)head;
+                        }
+                        const int maxlen = (int)(spq & kSpLenMask);
+                        if (maxlen >= kMatchMin) {
+                            bool veto = false;
+                            if (maxlen < kLazyLimit && cfg.lazy1 > 0) {
+                                const unsigned long long l1q = (unsigned long long)rl(l1_hi, sl) << 32 | rl(l1_lo, sl);
+                                if (l1q & acc) {
+                                    if (prof) n_lredo++;
+                                    veto = __builtin_amdgcn_readfirstlane((int)lazy_probe(dict, buf, q + 1, maxlen, cfg.lazy1)) != 0;
+                                } else veto = (spq & kSpVeto1) != 0;
+                                if (!veto && cfg.lazy2 > 0) {
+                                    const unsigned long long l2q = (unsigned long long)rl(l2_hi, sl) << 32 | rl(l2_lo, sl);
+                                    if (l2q & acc) veto = __builtin_amdgcn_readfirstlane((int)lazy_probe(dict, buf, q + 2, maxlen, cfg.lazy2)) != 0;
+                                    else veto = (spq & kSpVeto2) != 0;
+                                }
+                            }
+                            if (!veto) {
+                                is_match = true;
+                                mlen = maxlen;
+                                midx = (int)((head - ((spq >> kSpNodeShift) & (kRing - 1))) & (kRing - 1));
+                            }
+                        }
+                    }
+                }
+                if (is_match) {                      // src/libzling_lz.cpp:160-167
+                    emit((uint32_t)(258 + mlen - kMatchMin) | (uint32_t)midx << 16);
+                    opos += 2;
+                    q += mlen;
+                    if (q - P < 64) {
+                        const uint32_t xe = rl(x_end, q - P);
+                        const uint32_t cu = xe & 0xFF, w = xe >> 16, m = mru[cu];
+                        if ((m & 0xFFFF) != w) mru[cu] = (m << 16) | w;
+                    } else {
+                        pend = true;
+                    }
+                    continue;
+                }
+                const uint32_t xc = rl(x_chk, sl);
+                const uint32_t cq = xc & 0xFF, w = xc >> 16;
+                if (q + 1 < ilen) {                  // src/libzling_lz.cpp:172-185
+                    const uint32_t m = mru[cq];
+                    if ((m & 0xFFFF) == w) { emit(256); opos++; q += 2; continue; }
+                    if ((m >> 16) == w) { emit(257); opos++; q += 2; mru[cq] = (m << 16) | w; continue; }
+                }
+                emit((w >> 8) | cq << 16);           // literal, raw (rank stage K2), src/libzling_lz.cpp:188-191
+                opos++;
+                q++;
+                const uint32_t xl = rl(x_lit, sl);
+                const uint32_t cu = xl & 0xFF;
+                mru[cu] = (mru[cu] << 16) | (xl >> 16);
+            }
+            if (prof) c_p2 += __builtin_readcyclecounter() - t2;
+            // publish the ring heads advanced by this round (every accepted lane of a context writes the same value)
+            if (acc & lane_bit) heads[ctx] = (uint16_t)((head0 + (uint32_t)__popcll(ctxmask & acc)) & (kRing - 1));
+            __syncthreads();
+        }
+        if (nsub < kMaxSub && lane == 0) cuts[nsub] = SubCut{tok_begin, nt, (uint32_t)q, (uint32_t)opos};
+        nsub++;
+    }
+    if (lane < (int)(nt & 63)) tok[(nt & ~63u) + lane] = tokv;
+    if (lane == 0) { a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt; }
+    if (prof && lane == 0) {
+        unsigned long long* d = a.dbg + (size_t)blk * 16;
+        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_cand; d[6] = n_redo; d[7] = n_lredo;
+    }
+}
+
 void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s) {
-    launch_rolz_parse_serial(a, nblocks, s);   // TEMP until the wavefront parser lands
+    hipLaunchKernelGGL(k_rolz_parse_wave, dim3(nblocks), dim3(64), 0, s, a);
 }
 
 }  // namespace zlng

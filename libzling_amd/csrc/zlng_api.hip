@@ -60,6 +60,7 @@ struct zlng_ctx {
     uint64_t* d_summary = nullptr;
     uint8_t*  d_mtf = nullptr;        // live MTF tables (65,536 B)
     uint8_t*  d_mtf_saved = nullptr;  // tables at call entry (restored when a level re-run is needed)
+    unsigned long long* d_dbg = nullptr;  // parser phase counters (ZLNG_PROFILE=1)
 
     // host mirrors
     std::vector<uint8_t>  h_sched;
@@ -149,7 +150,7 @@ void launch_parse(zlng_ctx* c, const ParseArgs& pa, uint32_t nb) {
 // with a corrected schedule when the reference's level adaptation (src/libzling.cpp:261-266)
 // would have chosen differently.  At level 0 the schedule is always right (fallback == level).
 int run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, bool rank_now) {
-    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched};
+    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg};
     launch_dict_reset(c->d_dict, nb, c->stream);
     timer_mark(c, "dict_reset");
     launch_parse(c, pa, nb);
@@ -310,6 +311,11 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
         c->h_olen.resize(nsubs);
         c->h_cuts.resize(nsubs);
         c->h_blk_end.resize(nb);
+        const char* pf = getenv("ZLNG_PROFILE");
+        if (pf && pf[0] == '1') {
+            if ((rc = dev_alloc(c, &c->d_dbg, nb * 16))) return fail(rc);
+            if (hipMemset(c->d_dbg, 0, nb * 16 * sizeof(unsigned long long)) != hipSuccess) return fail(ZLNG_E_DEVICE);
+        }
     }
     uint8_t init[ZLNG_MTF_STATE];
     for (int ctx = 0; ctx < 256; ctx++) memcpy(init + 256 * ctx, k_mtfinit, 256);   // src/libzling_lz.cpp:106-111
@@ -322,7 +328,7 @@ void zlng_destroy(zlng_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
-                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved};
+                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved, c->d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -434,6 +440,13 @@ int zlng_last_timings(zlng_ctx* c, const char** names, float* ms, int cap) {
         ms[i] = t;
     }
     return n;
+}
+
+// Undocumented profiling aid (ZLNG_PROFILE=1): copies 16 counters per block of the last parse.
+int zlng_debug_counters(zlng_ctx* c, unsigned long long* out, int nblocks) {
+    if (!c || !c->d_dbg || nblocks > (int)c->max_blocks) return ZLNG_E_ARG;
+    CTX_HIP(hipMemcpy(out, c->d_dbg, (size_t)nblocks * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return ZLNG_OK;
 }
 
 void* zlng_stream(zlng_ctx* c) { return c ? (void*)c->stream : nullptr; }

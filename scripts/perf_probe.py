@@ -1,0 +1,44 @@
+"""Stage timing probe: python scripts/perf_probe.py [MiB] [level] -- prints per-stage device ms."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import torch
+import libzling_amd as zl
+from oracle_py import textgen, Oracle
+
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+check = "--check" in sys.argv
+n = mib << 20
+x = textgen(n, 0)
+nb = (n + zl.BLOCK - 1) // zl.BLOCK
+dx = torch.from_numpy(x).cuda()
+dx = torch.cat([dx, torch.zeros(512, dtype=torch.uint8, device="cuda")])
+cap = zl.encode_bound(n)
+dout = torch.empty(cap, dtype=torch.uint8, device="cuda")
+s = zl.Stream(0, level, True, nb)
+st0, lv0 = s.get_state()
+for it in range(2):
+    s.set_state(st0, lv0)
+    torch.cuda.synchronize()
+    t = time.time()
+    m = s.encode_device(dx.data_ptr(), n, dout.data_ptr(), cap)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    print("iter %d: %d -> %d bytes, %.1f ms, %.1f MB/s" % (it, n, m, dt * 1e3, n / dt / 1e6))
+    for name, ms in s.timings():
+        print("   %-14s %10.3f ms" % (name, ms))
+if os.environ.get("ZLNG_PROFILE") == "1":
+    import ctypes as C
+    buf = (C.c_ulonglong * (16 * nb))()
+    zl.lib().zlng_debug_counters(C.c_void_p(s._h), buf, nb)
+    for b in range(min(nb, 4)):
+        d = buf[16 * b: 16 * b + 8]
+        tot = d[0] + d[1] + d[2]
+        print("blk %d: cycles p1 %.0fM mask %.0fM p2 %.0fM | rounds %d tokens %d cand %d redo %d lazyredo %d | per round: p1 %.0f mask %.0f p2 %.0f cyc; per token p2 %.0f" % (
+            b, d[0] / 1e6, d[1] / 1e6, d[2] / 1e6, d[3], d[4], d[5], d[6], d[7], d[0] / max(d[3], 1), d[1] / max(d[3], 1), d[2] / max(d[3], 1), d[2] / max(d[4], 1)))
+if check:
+    z = dout[:m].cpu().numpy()
+    ref = Oracle().encode(x, level)
+    print("bit-exact vs oracle:", np.array_equal(z, ref))
