@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- encode MB/s (input) at e0 on an enwik9-shaped stream, bit-exact .zlng.
+
+    python bench.py [--gpus N --steps K --warmup W]            # N=1: this process, cuda:0
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole encode path (dictionary reset, ROLZ parse, MTF rank,
+histogram, Huffman lengths, layout, bit-pack + framing) over one 10^9-byte stream that is already
+resident in HBM, producing the complete .zlng in HBM.  Prints ONE JSON line on rank 0.
+
+Workload: real enwik9 if $ZLNG_ENWIK9 (or ./enwik9) exists, otherwise the deterministic synthetic
+text of libzling_amd/host/textgen.c at the same size (`data` says which).
+
+Multi-GPU (--shard streams, default): every rank encodes its own 10^9-byte stream (weak scaling,
+no data-path collective).  --shard single-stream instead shards ONE N x 10^9-byte stream by block
+ranges: each rank parses its range at once, the 64 KiB MTF state is handed from rank r to r+1 over
+RCCL (blocks of one stream are not independent), then rank + Huffman run per rank.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import libzling_amd as zl
+
+BLOCK = zl.BLOCK
+METRIC = "encode MB/s (input) at e0 on enwik9; bit-exact .zlng; 1/2/4/8 GPU"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def load_input(n, first_chunk):
+    """(array, source)."""
+    path = os.environ.get("ZLNG_ENWIK9", os.path.join(ROOT, "enwik9"))
+    if os.path.exists(path) and first_chunk == 0 and os.path.getsize(path) >= n:
+        return np.fromfile(path, dtype=np.uint8, count=n), "enwik9"
+    from oracle_py import textgen      # generator lives in libzling_amd/host; oracle_py only binds it
+    return textgen(n, first_chunk), "synthetic"
+
+
+def cpu_baseline(sample):
+    """Reference CPU encoder on `sample` bytes, 1 thread: (MB/s, kind, zlng)."""
+    from oracle_py import Oracle, Reference
+    if Reference.available():
+        enc, kind = Reference(), "reference"
+    else:
+        enc, kind = Oracle(), "port"
+    t = time.perf_counter()
+    z = enc.encode(sample, 0)
+    dt = time.perf_counter() - t
+    return sample.size / dt / 1e6, kind, z
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1_000_000_000, help="bytes per stream (enwik9 = 10^9)")
+    ap.add_argument("--level", type=int, default=0)
+    ap.add_argument("--shard", choices=["streams", "single-stream"], default="streams")
+    ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # ---- this rank's share of the workload
+    single = args.shard == "single-stream" and world > 1
+    if single:
+        per = ((args.size + BLOCK - 1) // BLOCK) * BLOCK           # inner ranks hold whole blocks
+        total = args.size * world
+        n = per if rank < world - 1 else total - per * (world - 1)
+        first_chunk = rank * (per // BLOCK)
+    else:
+        n = args.size
+        first_chunk = rank * 4096                                   # distinct stream per rank
+    x, source = load_input(n, first_chunk)
+    nb = (n + BLOCK - 1) // BLOCK
+    d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
+    d_in[:n].copy_(torch.from_numpy(x))
+    d_in[n:].zero_()
+    cap = zl.encode_bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_state = torch.empty(zl.MTF_STATE, dtype=torch.uint8, device="cuda")
+    stream = zl.Stream(local, args.level, True, nb)
+    init_state, init_level = stream.get_state()
+
+    def step():
+        if single:
+            stream.parse_device(d_in.data_ptr(), n)
+            if rank == 0:
+                stream.set_state(init_state, init_level)
+            else:
+                dist.recv(d_state, src=rank - 1)
+                torch.cuda.synchronize()
+                stream.set_state_device(d_state.data_ptr(), args.level)
+            m = stream.finish_device(d_out.data_ptr(), cap)
+            if rank < world - 1:
+                stream.get_state_device(d_state.data_ptr())
+                dist.send(d_state, dst=rank + 1)
+            return m
+        stream.set_state(init_state, init_level)                   # a fresh stream every step
+        return stream.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out_len = 0
+    for _ in range(args.warmup):
+        out_len = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_len = step()
+    fence()
+    dt = time.perf_counter() - t0
+    stage = dict(stream.timings())
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        sizes = torch.tensor([float(n), float(out_len)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+        total_in, total_out = float(sizes[0].item()), float(sizes[1].item())
+    else:
+        total_in, total_out = float(n), float(out_len)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_in * args.steps / dt / 1e6
+        # dominant kernel of the last step, from the HIP events the library records on its stream
+        dom = max(stage, key=stage.get) if stage else None
+        dom_ms = stage.get(dom, 0.0) if dom else 0.0
+        alg_bytes = float(n) + float(out_len)                       # every input byte read once,
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0   # every .zlng byte written once
+        res = {
+            "metric": METRIC, "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": source,
+            "config": {"workload": "enwik9-shaped %s text, %d B per stream, level e%d, %d blocks of 16 MiB in flight per GPU"
+                       % (source, args.size, args.level, nb),
+                       "shard": ("one stream sharded by block range, MTF state hand-off over RCCL" if single
+                                 else "one independent stream per GPU"),
+                       "input_bytes_total": int(total_in), "zlng_bytes_total": int(total_out)},
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 3),
+                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None},
+            "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sample_n = min(n, (args.cpu_sample_mib << 20) // BLOCK * BLOCK) or n
+            mbs, kind, z = cpu_baseline(x[:sample_n])
+            got = d_out[: z.size].cpu().numpy()
+            # the .zlng of a whole-block prefix is a prefix of the stream's .zlng (state only flows forward)
+            res["parity"] = bool(np.array_equal(got, z))
+            res["cpu_baseline"] = {"value": round(mbs, 2), "unit": "MB/s", "cores": 1, "kind": kind,
+                                   "sample": "first %d MiB of the same stream, e%d, single thread, "
+                                             "GPU output prefix compared byte-for-byte" % (sample_n >> 20, args.level)}
+        res["zlng_sha256_rank0"] = hashlib.sha256(d_out[:out_len].cpu().numpy().tobytes()).hexdigest()
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

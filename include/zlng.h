@@ -99,6 +99,9 @@ int zlng_encode_finish_device(zlng_ctx*, void* d_out, size_t out_cap, size_t* ou
 /* Stream state hand-off: 65,536 bytes of MTF tables (context-major) + current_level. */
 int zlng_get_state(zlng_ctx*, uint8_t mtf[ZLNG_MTF_STATE], int* current_level);
 int zlng_set_state(zlng_ctx*, const uint8_t mtf[ZLNG_MTF_STATE], int current_level);
+/* Same with the 65,536 table bytes in this device's HBM (e.g. the buffer of an RCCL send/recv). */
+int zlng_get_state_device(zlng_ctx*, void* d_mtf, int* current_level);
+int zlng_set_state_device(zlng_ctx*, const void* d_mtf, int current_level);
 
 /* Decode a stream prefix made of whole blocks from HOST memory; *in_used gets the bytes consumed. */
 int zlng_decode_blocks(zlng_ctx*, const uint8_t* in, size_t in_len, size_t* in_used,

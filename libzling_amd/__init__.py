@@ -26,6 +26,28 @@ class ZlngError(RuntimeError):
         super().__init__("zlng error %d (%s) %s" % (code, strerror(code), what))
 
 
+def _preload_torch_hip_runtime():
+    """A process must run ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64.so.7 (same
+    soname as /opt/rocm's, which libzlng_hip.so links): whichever is loaded first serves both.
+    torch cannot initialise on the system copy, so when torch is installed make its copy the
+    process-wide one before libzlng_hip.so is opened (a no-op if torch is already imported)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    tl = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(tl, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load libzlng_hip.so (built in-tree by libzling_amd.build / __graft_entry__.build)."""
     global _lib
@@ -33,6 +55,7 @@ def lib():
         if not os.path.exists(HIP_SO):
             raise ImportError("libzlng_hip.so is not built: run `python -m libzling_amd.build` "
                               "(there is no fallback implementation)")
+        _preload_torch_hip_runtime()
         L = C.CDLL(HIP_SO)
         L.zlng_device_count.restype = C.c_int
         L.zlng_create.restype = C.c_void_p
@@ -46,6 +69,8 @@ def lib():
         L.zlng_encode_finish_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _szp, _szp]
         L.zlng_get_state.argtypes = [C.c_void_p, _u8p, C.POINTER(C.c_int)]
         L.zlng_set_state.argtypes = [C.c_void_p, _u8p, C.c_int]
+        L.zlng_get_state_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.zlng_set_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.zlng_decode_blocks.argtypes = [C.c_void_p, _u8p, C.c_size_t, _szp, _u8p, C.c_size_t, _szp, _szp]
         L.zlng_decode_blocks_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _szp, C.c_void_p, C.c_size_t, _szp, _szp]
         L.zlng_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
@@ -81,9 +106,9 @@ class Stream:
         self.level = level
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().zlng_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.zlng_destroy(h)
 
     __del__ = close
 
@@ -155,6 +180,34 @@ class Stream:
         rc = lib().zlng_set_state(self._h, _ptr(mtf), level)
         if rc != 0:
             raise ZlngError(rc, "zlng_set_state")
+
+    def get_state_device(self, d_ptr):
+        lv = C.c_int(0)
+        rc = lib().zlng_get_state_device(self._h, d_ptr, C.byref(lv))
+        if rc != 0:
+            raise ZlngError(rc, "zlng_get_state_device")
+        return lv.value
+
+    def set_state_device(self, d_ptr, level):
+        rc = lib().zlng_set_state_device(self._h, d_ptr, level)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_set_state_device")
+
+    def debug_fetch(self, what, blk, dtype, count):
+        """Test hook (zlng_debug_fetch): internal buffer `what` of block `blk` after the last encode."""
+        out = np.empty(count, dtype=dtype)
+        f = lib().zlng_debug_fetch
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        rc = f(self._h, what, blk, out.ctypes.data, out.nbytes)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_debug_fetch")
+        return out
+
+    def block_tokens(self, blk):
+        ntok, nsub = self.debug_fetch(5, blk, np.uint32, 2)
+        tok = self.debug_fetch(0, blk, np.uint32, int(ntok))
+        cuts = self.debug_fetch(1, blk, np.uint32, 4 * int(nsub)).reshape(-1, 4)
+        return tok, cuts
 
     def timings(self):
         names = (C.c_char_p * 16)()

@@ -9,6 +9,7 @@
 // Sub-blocks are independent here, so the grid is (sub-block, block).
 #include "zlng_common.h"
 #include "zlng_kernels.h"
+#include <cstdlib>
 
 namespace zlng {
 
@@ -299,6 +300,8 @@ __global__ __launch_bounds__(kPackThreads) void k_pack(HuffArgs a) {
     const uint32_t* t = a.tok + (size_t)blk * kTokCap;
     for (uint32_t base = c.tok_begin; ; base += kPackTile) {
         // flush completed words, slide the window
+        cur = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cur >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cur);
         const uint32_t nfull = (uint32_t)(cur >> 5);
         if (nfull) {
             win_flush(win, nfull, a.out, g0, lo, hi);
@@ -357,7 +360,9 @@ void launch_layout(const HuffArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, s, a);
 }
 void launch_pack(const HuffArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_pack, dim3(kMaxSub, a.nblocks), dim3(kPackThreads), 0, s, a);
+    const char* e = getenv("ZLNG_DEBUG_PACK_LDS");
+    const unsigned dyn = e ? (unsigned)atoi(e) : 0u;
+    hipLaunchKernelGGL(k_pack, dim3(kMaxSub, a.nblocks), dim3(kPackThreads), dyn, s, a);
 }
 
 }  // namespace zlng

@@ -421,6 +421,24 @@ int zlng_set_state(zlng_ctx* c, const uint8_t mtf[ZLNG_MTF_STATE], int current_l
     return ZLNG_OK;
 }
 
+int zlng_get_state_device(zlng_ctx* c, void* d_mtf, int* current_level) {
+    if (!c || !d_mtf) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    CTX_HIP(hipMemcpyAsync(d_mtf, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    if (current_level) *current_level = c->current_level;
+    return ZLNG_OK;
+}
+
+int zlng_set_state_device(zlng_ctx* c, const void* d_mtf, int current_level) {
+    if (!c || !d_mtf || current_level < 0 || current_level > 4) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    CTX_HIP(hipMemcpyAsync(c->d_mtf, d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    c->current_level = current_level;
+    return ZLNG_OK;
+}
+
 int zlng_decode_blocks(zlng_ctx*, const uint8_t*, size_t, size_t*, uint8_t*, size_t, size_t*, size_t*) {
     return ZLNG_E_DEVICE;   // decode kernels: see decode.hip (not linked in this build)
 }
@@ -440,6 +458,39 @@ int zlng_last_timings(zlng_ctx* c, const char** names, float* ms, int cap) {
         ms[i] = t;
     }
     return n;
+}
+
+// Test hook: copy an internal per-block buffer of the last encode call to the host, so the
+// stage-level parity tests can compare each kernel with the oracle's stage API.
+//   what: 0 tokens (u32 x ntok), 1 cuts (SubCut x nsub), 2 freq (u32 x 546 per sub-block, kMaxSub rows),
+//         3 lens (u8 x 546 rows), 4 olen (u32 x kMaxSub), 5 ntok/nsub (2 x u32), 6 codes (u16 x 546 rows),
+//         7 sub-block output offsets (u64 x kMaxSub)
+int zlng_debug_fetch(zlng_ctx* c, int what, int blk, void* dst, size_t bytes) {
+    if (!c || !c->is_encode || blk < 0 || (uint32_t)blk >= c->max_blocks || !dst) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    const void* src = nullptr;
+    size_t cap = 0;
+    uint32_t two[2];
+    switch (what) {
+        case 0: src = c->d_tok + (size_t)blk * kTokCap; cap = kTokCap * 4; break;
+        case 1: src = c->d_cuts + (size_t)blk * kMaxSub; cap = sizeof(SubCut) * kMaxSub; break;
+        case 2: src = c->d_freq + (size_t)blk * kMaxSub * kNsymAll; cap = (size_t)kMaxSub * kNsymAll * 4; break;
+        case 3: src = c->d_lens + (size_t)blk * kMaxSub * kNsymAll; cap = (size_t)kMaxSub * kNsymAll; break;
+        case 4: src = c->d_olen + (size_t)blk * kMaxSub; cap = (size_t)kMaxSub * 4; break;
+        case 6: src = c->d_codes + (size_t)blk * kMaxSub * kNsymAll; cap = (size_t)kMaxSub * kNsymAll * 2; break;
+        case 7: src = c->d_sub_off + (size_t)blk * kMaxSub; cap = (size_t)kMaxSub * 8; break;
+        case 5:
+            CTX_HIP(hipMemcpy(&two[0], c->d_ntok + blk, 4, hipMemcpyDeviceToHost));
+            CTX_HIP(hipMemcpy(&two[1], c->d_nsub + blk, 4, hipMemcpyDeviceToHost));
+            if (bytes < 8) return ZLNG_E_ARG;
+            memcpy(dst, two, 8);
+            return ZLNG_OK;
+        default: return ZLNG_E_ARG;
+    }
+    if (bytes > cap) return ZLNG_E_ARG;
+    CTX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return ZLNG_OK;
 }
 
 // Undocumented profiling aid (ZLNG_PROFILE=1): copies 16 counters per block of the last parse.
