@@ -68,10 +68,23 @@ def build_shim(force=False):
     return SHIM_SO
 
 
+DEMO = os.path.join(ROOT, "tools", "zling_demo")
+
+
+def build_demo(force=False):
+    src = os.path.join(ROOT, "tools", "zling_demo.cpp")
+    if force or _stale(DEMO, [src, SHIM_SO]):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include", "libzling"),
+                               "-I", os.path.join(ROOT, "include"), "-o", DEMO, src, "-L", PKG, "-lzling_amd", "-lzlng_hip",
+                               "-Wl,-rpath," + PKG, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return DEMO
+
+
 def build_all(force=False, verbose=False):
     build_textgen(force)
     build_hip(force, verbose)
     build_shim(force)
+    build_demo(force)
 
 
 if __name__ == "__main__":

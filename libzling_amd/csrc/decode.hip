@@ -1,0 +1,264 @@
+// decode.hip -- K7 frame walk, K8 Huffman decode, K9 ROLZ + MTF replay: the inverse path.
+//
+// Replaces the body of baidu::zling::Decode (src/libzling.cpp:306-420):
+//   framing walk / size checks        src/libzling.cpp:312-332
+//   length tables -> decode LUTs      src/libzling.cpp:347-365, src/libzling_huffman.cpp:114-153
+//   symbol loop                       src/libzling.cpp:368-402
+//   ZlingRolzDecoder::Decode          src/libzling_lz.cpp:318-399  (+ ZlingMTFDecoder :119-126)
+//
+// Parallel structure: sub-block headers are hop-able (olen), so one lane walks them; Huffman
+// decode is independent per sub-block (one wavefront each, 15-bit LUT in LDS); the ROLZ replay is
+// serial per block AND -- because the literal MTF tables persist across blocks and the context of
+// a literal is decoded data -- serial across the whole stream.  K9 is
+// therefore one wavefront per stream; its lanes cooperate on the match copies.
+#include "zlng_common.h"
+#include "zlng_kernels.h"
+
+namespace zlng {
+
+// ------------------------------------------------------------------------------ K7 frame walk
+__global__ __launch_bounds__(64) void k_frame_walk(DecodeArgs a) {
+    if (threadIdx.x != 0) return;
+    const uint8_t* z = a.z;
+    const uint64_t n = a.z_len;
+    uint64_t p = 0, used = 0, out_total = 0, tok_total = 0;
+    uint32_t nblk = 0, nsub = 0, err = 0;
+    while (p < n && nblk < a.max_blocks && !err) {
+        const uint32_t first_sub = nsub;
+        uint32_t last_encpos = 0;
+        bool closed = false;
+        while (p < n) {
+            const uint32_t flag = z[p++];
+            if (flag != 0 && flag != 1) { err = (uint32_t)(-ZLNG_DEC_E_FLAG); break; }
+            if (flag == 0) { closed = true; break; }
+            if (p + 12 > n) break;                                   // header cut: block incomplete
+            auto be32 = [&](uint64_t o) { return (uint32_t)z[o] << 24 | (uint32_t)z[o + 1] << 16 | (uint32_t)z[o + 2] << 8 | z[o + 3]; };
+            const uint32_t encpos = be32(p), rlen = be32(p + 4), olen = be32(p + 8);
+            p += 12;
+            if (rlen > (uint32_t)kSubSyms || olen > (uint32_t)kPayloadMax) { err = (uint32_t)(-ZLNG_DEC_E_BLOCKSIZE); break; }
+            if (olen < (uint32_t)kTableBytes || encpos > (uint32_t)kBlockIn || encpos < last_encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+            if (p + olen > n) break;                                 // payload cut: block incomplete
+            if (nsub >= a.max_subs) { err = (uint32_t)(-ZLNG_DEC_E_LIMIT); break; }
+            if (tok_total + rlen > a.tok_cap || out_total + encpos > a.out_cap) { err = (uint32_t)(-ZLNG_DEC_E_LIMIT); break; }
+            a.subs[nsub] = DecSub{p, tok_total, encpos, rlen, olen, nblk};
+            nsub++;
+            tok_total += rlen;
+            p += olen;
+            last_encpos = encpos;
+        }
+        if (err || !closed) { nsub = first_sub; break; }             // drop the incomplete block
+        a.blocks[nblk] = DecBlock{first_sub, nsub - first_sub, out_total, last_encpos, 0};
+        out_total += last_encpos;
+        nblk++;
+        used = p;
+    }
+    a.summary[0] = used;
+    a.summary[1] = err;
+    a.summary[2] = nblk;
+    a.summary[3] = nsub;
+    a.summary[4] = out_total;
+}
+
+// ------------------------------------------------------------------------------ K8 Huffman decode
+// One wavefront per sub-block.  The 64 lanes build the 2^15-entry LUT of alphabet 1 and the 2^8
+// LUT of alphabet 2 in LDS, then stream the payload through a 256-byte register window (lane l
+// holds dword l; the next window is already in flight) while the symbol loop runs wave-uniformly.
+constexpr int kLut1Bits = kMaxLen1, kLut2Bits = kMaxLen2;
+
+__device__ void build_codes_lane0(const uint8_t* len, uint16_t* code, int n, int limit) {   // src/libzling_huffman.cpp:114-138
+    uint32_t next[16];
+    uint32_t count[16];
+    for (int l = 0; l < 16; l++) count[l] = 0;
+    for (int i = 0; i < n; i++) count[len[i]]++;
+    uint32_t c = 0;
+    for (int l = 1; l <= limit; l++) { next[l] = c; c = (c + count[l]) * 2; }
+    for (int i = 0; i < n; i++) {
+        const uint32_t l = len[i];
+        code[i] = l ? (uint16_t)((__brev(next[l]++) >> 16 & 0xFFFFu) >> (16 - l)) : (uint16_t)0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
+    __shared__ uint16_t lut1[1 << kLut1Bits];
+    __shared__ uint16_t lut2[1 << kLut2Bits];
+    __shared__ uint8_t  len[kNsymAll + 2];
+    __shared__ uint16_t code[kNsymAll];
+    const uint32_t s = blockIdx.x;
+    if (s >= (uint32_t)a.summary[3] || a.summary[1] != 0) return;
+    const DecSub sb = a.subs[s];
+    const uint8_t* pay = a.z + sb.payload_off;
+    const uint32_t lane = threadIdx.x;
+
+    // nibble tables (src/libzling.cpp:347-356)
+    for (uint32_t j = lane; j < (uint32_t)kTableBytes; j += 64) {
+        const uint32_t b = pay[j];
+        const uint32_t s0 = j < 257 ? 2 * j : kNsym1 + 2 * (j - 257);
+        len[s0] = (uint8_t)(b >> 4);
+        len[s0 + 1] = (uint8_t)(b & 15);
+    }
+    for (uint32_t i = lane; i < (1u << kLut1Bits); i += 64) lut1[i] = 0xFFFF;
+    for (uint32_t i = lane; i < (1u << kLut2Bits); i += 64) lut2[i] = 0xFFFF;
+    __syncthreads();
+    if (lane == 0) {
+        build_codes_lane0(len, code, kNsym1, kMaxLen1);
+        build_codes_lane0(len + kNsym1, code + kNsym1, kNsym2, kMaxLen2);
+    }
+    __syncthreads();
+    // ZlingMakeDecodeTable (src/libzling_huffman.cpp:140-153)
+    for (uint32_t c = lane; c < (uint32_t)kNsym1; c += 64) {
+        const uint32_t l = len[c];
+        if (l > 0 && l <= (uint32_t)kLut1Bits) for (uint32_t i = code[c]; i < (1u << kLut1Bits); i += 1u << l) lut1[i] = (uint16_t)c;
+    }
+    for (uint32_t c = lane; c < (uint32_t)kNsym2; c += 64) {
+        const uint32_t l = len[kNsym1 + c];
+        if (l > 0 && l <= (uint32_t)kLut2Bits) for (uint32_t i = code[kNsym1 + c]; i < (1u << kLut2Bits); i += 1u << l) lut2[i] = (uint16_t)c;
+    }
+    __syncthreads();
+
+    // bitstream starts right after the tables; bytes past olen read as zero (the reference reads
+    // whatever follows in obuf; a valid stream never consumes them)
+    const uint32_t nbytes = sb.olen - kTableBytes;
+    const uint8_t* bits = pay + kTableBytes;
+    auto load_win = [&](uint32_t w) -> uint32_t {                    // dword (64 w + lane) of the bitstream
+        const uint32_t o = (w * 64 + lane) * 4;
+        uint32_t v = 0;
+        if (o + 4 <= nbytes) __builtin_memcpy(&v, bits + o, 4);
+        else for (uint32_t k = 0; k < 4; k++) if (o + k < nbytes) v |= (uint32_t)bits[o + k] << (8 * k);
+        return v;
+    };
+    uint32_t win = load_win(0), win_next = load_win(1);
+    uint32_t widx = 0;                                               // next dword to pull (wave-uniform)
+    uint64_t acc = 0;
+    int nb = 0;
+    uint32_t* tok = a.tok + sb.tok_off;
+    uint32_t nt = 0, tokv = 0, err = 0;
+    for (uint32_t i = 0; i < sb.rlen; i++) {
+        if (nb < 32) {                                               // src/libzling.cpp:369-374
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(widx & 63));
+            acc |= (uint64_t)w << nb;
+            nb += 32;
+            widx++;
+            if ((widx & 63) == 0) { win = win_next; win_next = load_win((widx >> 6) + 1); }
+        }
+        const uint32_t sym = lut1[(uint32_t)acc & ((1u << kLut1Bits) - 1)];
+        if (sym >= (uint32_t)kNsym1) { err = (uint32_t)(-ZLNG_DEC_E_CODE1); break; }
+        const uint32_t l1 = len[sym];
+        acc >>= l1; nb -= (int)l1;
+        uint32_t t = sym;
+        if (sym >= 258) {                                            // src/libzling.cpp:386-401
+            const uint32_t c = lut2[(uint32_t)acc & ((1u << kLut2Bits) - 1)];
+            if (c >= (uint32_t)kNsym2) { err = (uint32_t)(-ZLNG_DEC_E_CODE2); break; }
+            const uint32_t l2 = len[kNsym1 + c];
+            acc >>= l2; nb -= (int)l2;
+            const uint32_t bl = matchidx_blen_of_code(c);
+            const uint32_t ex = (uint32_t)acc & ((1u << bl) - 1u);
+            acc >>= bl; nb -= (int)bl;
+            const uint32_t base = c < 4 ? c : (c < 18 ? (2u + (c & 1u)) << ((c >> 1) - 1) : (c - 16) << 8);
+            const uint32_t idx = base + ex;
+            if (idx >= (uint32_t)kRing || i + 1 >= sb.rlen) { err = (uint32_t)(-ZLNG_DEC_E_EXBITS); break; }
+            t |= idx << 16;
+            i++;                                                     // a match occupies two u16 entries
+        }
+        tokv = lane == (nt & 63) ? t : tokv;
+        nt++;
+        if ((nt & 63) == 0) tok[nt - 64 + lane] = tokv;
+    }
+    if (lane < (nt & 63)) tok[(nt & ~63u) + lane] = tokv;
+    if (lane == 0) {
+        a.sub_ntok[s] = nt;
+        if (err) atomicCAS((unsigned long long*)&a.summary[1], 0ull, (unsigned long long)err);
+    }
+}
+
+// ------------------------------------------------------------------------------ K9 ROLZ + MTF replay
+// One wavefront per stream.  Control flow is wave-uniform (every lane follows the same token);
+// lane 0 performs the scalar stores, all lanes share the match copies.
+__global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
+    __shared__ uint8_t  mtf[256 * 256];
+    __shared__ uint32_t mru[256];
+    __shared__ uint16_t heads[256];
+    const uint32_t lane = threadIdx.x;
+    if (a.summary[1] != 0) return;
+    const uint32_t nblk = (uint32_t)a.summary[2];
+    for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(mtf)[i] = reinterpret_cast<const uint32_t*>(a.mtf_state)[i];
+    __syncthreads();
+    uint32_t err = 0;
+    uint32_t* ring = a.ring;                                          // [256][4096] source positions
+    for (uint32_t b = 0; b < nblk && !err; b++) {
+        const DecBlock bk = a.blocks[b];
+        uint8_t* out = a.out + bk.out_off;
+        for (uint32_t i = lane; i < 256u * kRing; i += 64) ring[i] = 0;    // Reset(), src/libzling_lz.cpp:378-386
+        for (uint32_t i = lane; i < 256; i += 64) heads[i] = 0;
+        __syncthreads();
+        uint32_t opos = 0;
+        for (uint32_t k = 0; k < bk.nsub && !err; k++) {
+            const DecSub sb = a.subs[bk.first_sub + k];
+            const uint32_t* tok = a.tok + sb.tok_off;
+            const uint32_t nt = a.sub_ntok[bk.first_sub + k];
+            for (uint32_t i = lane; i < 256; i += 64) mru[i] = 0;
+            __syncthreads();
+            uint32_t ti = 0;
+            // first two bytes of a block are raw (src/libzling_lz.cpp:327-328)
+            while (opos < 2 && ti < nt) {
+                const uint32_t v = tok[ti++];
+                if ((v & 0xFFFF) >= 256 || opos + 1 > sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+                if (lane == 0) out[opos] = (uint8_t)v;
+                opos++;
+            }
+            while (ti < nt && !err) {
+                const uint32_t v = tok[ti++], sym = v & 0xFFFF;
+                const uint32_t c1 = out[opos - 1];                    // order-1 context
+                // GetMatchAndUpdate: every token inserts its start position (src/libzling_lz.cpp:388-399)
+                const uint32_t head = (heads[c1] + 1u) & (kRing - 1);
+                uint32_t* r = ring + c1 * kRing;
+                const uint32_t src = sym >= 258 ? r[(head - (v >> 16)) & (kRing - 1)] : 0;
+                if (lane == 0) { heads[c1] = (uint16_t)head; r[head] = opos; }
+                if (sym < 256) {                                      // literal: ZlingMTFDecoder::Decode :122-126
+                    if (opos + 1 > sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+                    uint8_t* t = mtf + c1 * 256;
+                    const uint32_t nx = mtf_next(sym);
+                    const uint8_t cc = t[sym], dd = t[nx];
+                    if (lane == 0) { t[sym] = dd; t[nx] = cc; out[opos] = cc; }
+                    opos++;
+                    const uint32_t cu = out[opos - 3];
+                    if (lane == 0) mru[cu] = (mru[cu] << 16) | (c1 << 8 | cc);
+                } else if (sym < 258) {                               // word MRU slot 0 / 1
+                    if (opos + 2 > sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+                    const uint32_t m = mru[c1];
+                    const uint32_t w = sym == 256 ? (m & 0xFFFF) : (m >> 16);
+                    if (lane == 0) {
+                        out[opos] = (uint8_t)(w >> 8); out[opos + 1] = (uint8_t)w;
+                        if (sym == 257) mru[c1] = (m << 16) | w;
+                    }
+                    opos += 2;
+                } else {                                              // match
+                    const uint32_t mlen = sym - 258 + kMatchMin;
+                    if (opos + mlen > sb.encpos || src >= opos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+                    const uint32_t dist = opos - src;
+                    if (dist >= 64 || dist >= mlen) {
+                        for (uint32_t j = lane; j < mlen; j += 64) out[opos + j] = out[src + j];
+                    } else {                                          // overlapping: period `dist` (forward byte copy, :91-104)
+                        for (uint32_t j = lane; j < mlen; j += 64) out[opos + j] = out[src + j % dist];
+                    }
+                    opos += mlen;
+                    const uint32_t cu = out[opos - 3], w = (uint32_t)out[opos - 2] << 8 | out[opos - 1];
+                    const uint32_t m = mru[cu];
+                    if (lane == 0 && (m & 0xFFFF) != w) mru[cu] = (m << 16) | w;
+                }
+            }
+            if (!err && opos != sb.encpos) err = (uint32_t)(-ZLNG_DEC_E_LZ);   // src/libzling_lz.cpp:371-373
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_state)[i] = reinterpret_cast<const uint32_t*>(mtf)[i];
+    if (lane == 0 && err) a.summary[1] = err;
+}
+
+void launch_frame_walk(const DecodeArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, s, a); }
+void launch_huff_decode(const DecodeArgs& a, uint32_t nsubs_upper, hipStream_t s) {
+    hipLaunchKernelGGL(k_huff_decode, dim3(nsubs_upper), dim3(64), 0, s, a);
+}
+void launch_rolz_decode(const DecodeArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_rolz_decode, dim3(1), dim3(64), 0, s, a); }
+
+}  // namespace zlng

@@ -61,6 +61,12 @@ struct zlng_ctx {
     uint8_t*  d_mtf = nullptr;        // live MTF tables (65,536 B)
     uint8_t*  d_mtf_saved = nullptr;  // tables at call entry (restored when a level re-run is needed)
     unsigned long long* d_dbg = nullptr;  // parser phase counters (ZLNG_PROFILE=1)
+    // decode pools
+    DecSub*   d_subs = nullptr;
+    DecBlock* d_blocks = nullptr;
+    uint32_t* d_sub_ntok = nullptr;
+    uint32_t* d_ring = nullptr;
+    std::vector<DecBlock> h_blocks;
 
     // host mirrors
     std::vector<uint8_t>  h_sched;
@@ -297,6 +303,14 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     for (int i = 0; i <= kMaxStages; i++) if (hipEventCreate(&c->timer.ev[i]) != hipSuccess) return fail(ZLNG_E_DEVICE);
     const size_t nb = (size_t)max_blocks, nsubs = nb * kMaxSub;
     if ((rc = dev_alloc(c, &c->d_mtf, ZLNG_MTF_STATE)) || (rc = dev_alloc(c, &c->d_mtf_saved, ZLNG_MTF_STATE))) return fail(rc);
+    if (!c->is_encode) {
+        const size_t max_subs = nb * kDecSubsPerBlock;
+        if ((rc = dev_alloc(c, &c->d_subs, max_subs)) || (rc = dev_alloc(c, &c->d_blocks, nb)) ||
+            (rc = dev_alloc(c, &c->d_sub_ntok, max_subs)) || (rc = dev_alloc(c, &c->d_ring, (size_t)256 * kRing)) ||
+            (rc = dev_alloc(c, &c->d_tok, nb * (kTokCap + 64))) || (rc = dev_alloc(c, &c->d_summary, 8)))
+            return fail(rc);
+        c->h_blocks.resize(nb);
+    }
     if (c->is_encode) {
         if ((rc = dev_alloc(c, &c->d_dict, nb * kDictBytes)) || (rc = dev_alloc(c, &c->d_tok, nb * kTokCap)) ||
             (rc = dev_alloc(c, &c->d_cuts, nsubs)) || (rc = dev_alloc(c, &c->d_nsub, nb)) ||
@@ -304,7 +318,7 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
             (rc = dev_alloc(c, &c->d_freq, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_lens, nsubs * kNsymAll)) ||
             (rc = dev_alloc(c, &c->d_codes, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_olen, nsubs)) ||
             (rc = dev_alloc(c, &c->d_sub_off, nsubs)) || (rc = dev_alloc(c, &c->d_blk_end, nb)) ||
-            (rc = dev_alloc(c, &c->d_summary, 4)))
+            (rc = dev_alloc(c, &c->d_summary, 8)))
             return fail(rc);
         c->h_sched.resize(nsubs);
         c->h_nsub.resize(nb);
@@ -328,7 +342,7 @@ void zlng_destroy(zlng_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
-                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved, c->d_dbg};
+                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -439,11 +453,65 @@ int zlng_set_state_device(zlng_ctx* c, const void* d_mtf, int current_level) {
     return ZLNG_OK;
 }
 
-int zlng_decode_blocks(zlng_ctx*, const uint8_t*, size_t, size_t*, uint8_t*, size_t, size_t*, size_t*) {
-    return ZLNG_E_DEVICE;   // decode kernels: see decode.hip (not linked in this build)
+static_assert(ZLNG_DEC_E_FLAG == ZLNG_E_FLAG && ZLNG_DEC_E_BLOCKSIZE == ZLNG_E_BLOCKSIZE && ZLNG_DEC_E_CODE1 == ZLNG_E_CODE1 &&
+              ZLNG_DEC_E_CODE2 == ZLNG_E_CODE2 && ZLNG_DEC_E_EXBITS == ZLNG_E_EXBITS && ZLNG_DEC_E_LZ == ZLNG_E_LZ &&
+              ZLNG_DEC_E_LIMIT == ZLNG_E_ARG, "device-side error codes must match zlng.h");
+
+int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size_t* in_used, void* d_out, size_t out_cap,
+                              size_t* out_len, size_t* per_block_out_end) {
+    if (!c || c->is_encode || !in_used || !out_len) return ZLNG_E_ARG;
+    *in_used = 0;
+    *out_len = 0;
+    if (in_len == 0) return ZLNG_OK;
+    if (!d_in || !d_out) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    timer_begin(c);
+    DecodeArgs da{static_cast<const uint8_t*>(d_in), (uint64_t)in_len, c->max_blocks, c->max_blocks * kDecSubsPerBlock,
+                  (uint64_t)c->max_blocks * (kTokCap + 64), c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_tok, c->d_ring,
+                  c->d_mtf, static_cast<uint8_t*>(d_out), (uint64_t)out_cap, c->d_summary};
+    launch_frame_walk(da, c->stream);
+    timer_mark(c, "frame_walk");
+    uint64_t sum[5] = {0, 0, 0, 0, 0};
+    CTX_HIP(hipMemcpyAsync(sum, c->d_summary, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    if (sum[1]) return -(int)sum[1];
+    const uint32_t nblk = (uint32_t)sum[2], nsub = (uint32_t)sum[3];
+    if (nblk == 0) return ZLNG_E_TRUNC;                   // not even one complete block in the prefix
+    launch_huff_decode(da, nsub, c->stream);
+    timer_mark(c, "huff_decode");
+    launch_rolz_decode(da, c->stream);
+    timer_mark(c, "rolz_decode");
+    CTX_HIP(hipMemcpyAsync(sum, c->d_summary, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipMemcpyAsync(c->h_blocks.data(), c->d_blocks, nblk * sizeof(DecBlock), hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    CTX_HIP(hipGetLastError());
+    if (sum[1]) return -(int)sum[1];
+    *in_used = (size_t)sum[0];
+    *out_len = (size_t)sum[4];
+    if (per_block_out_end) for (uint32_t b = 0; b < nblk; b++) per_block_out_end[b] = (size_t)(c->h_blocks[b].out_off + c->h_blocks[b].size);
+    return ZLNG_OK;
 }
-int zlng_decode_blocks_device(zlng_ctx*, const void*, size_t, size_t*, void*, size_t, size_t*, size_t*) {
-    return ZLNG_E_DEVICE;
+
+int zlng_decode_blocks(zlng_ctx* c, const uint8_t* in, size_t in_len, size_t* in_used, uint8_t* out, size_t out_cap,
+                       size_t* out_len, size_t* per_block_out_end) {
+    if (!c || c->is_encode || !in_used || !out_len) return ZLNG_E_ARG;
+    *in_used = 0;
+    *out_len = 0;
+    if (in_len == 0) return ZLNG_OK;
+    if (!in || !out) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    int rc;
+    const size_t raw_cap = (size_t)c->max_blocks * kBlockIn;
+    if ((rc = ensure_in(c, in_len + 512)) || (rc = ensure_out(c, raw_cap + 512))) return rc;
+    CTX_HIP(hipMemcpyAsync(c->d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+    size_t produced = 0;
+    rc = zlng_decode_blocks_device(c, c->d_in, in_len, in_used, c->d_out, raw_cap, &produced, per_block_out_end);
+    if (rc != ZLNG_OK) return rc;
+    if (produced > out_cap) { *in_used = 0; return ZLNG_E_CAP; }
+    CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    *out_len = produced;
+    return ZLNG_OK;
 }
 
 int zlng_last_timings(zlng_ctx* c, const char** names, float* ms, int cap) {

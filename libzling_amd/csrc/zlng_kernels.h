@@ -50,4 +50,31 @@ void launch_lengths(const HuffArgs& a, hipStream_t s);
 void launch_layout(const HuffArgs& a, hipStream_t s);
 void launch_pack(const HuffArgs& a, hipStream_t s);
 
+// ---- K7..K9 (decode) --------------------------------------------------------------------
+// error codes as in include/zlng.h (kept numerically identical; checked by static_assert in zlng_api.hip)
+constexpr int ZLNG_DEC_E_LIMIT = -1, ZLNG_DEC_E_FLAG = -10, ZLNG_DEC_E_BLOCKSIZE = -11, ZLNG_DEC_E_CODE1 = -12,
+              ZLNG_DEC_E_CODE2 = -13, ZLNG_DEC_E_EXBITS = -14, ZLNG_DEC_E_LZ = -15;
+constexpr uint32_t kDecSubsPerBlock = 1024;      // sub-block table capacity per block of a decode call
+
+struct DecSub   { uint64_t payload_off, tok_off; uint32_t encpos, rlen, olen, blk; };
+struct DecBlock { uint32_t first_sub, nsub; uint64_t out_off; uint32_t size, pad; };
+struct DecodeArgs {
+    const uint8_t* z;          // compressed bytes
+    uint64_t       z_len;
+    uint32_t       max_blocks, max_subs;
+    uint64_t       tok_cap;    // token words available
+    DecSub*        subs;
+    DecBlock*      blocks;
+    uint32_t*      sub_ntok;
+    uint32_t*      tok;
+    uint32_t*      ring;       // [256][4096] ZlingDecodeBucket::offset (src/libzling_lz.h:132-135)
+    uint8_t*       mtf_state;  // 256 x 256, persists across calls
+    uint8_t*       out;
+    uint64_t       out_cap;
+    uint64_t*      summary;    // [0] bytes consumed [1] error (positive code) [2] blocks [3] sub-blocks [4] output bytes
+};
+void launch_frame_walk(const DecodeArgs& a, hipStream_t s);
+void launch_huff_decode(const DecodeArgs& a, uint32_t nsubs, hipStream_t s);
+void launch_rolz_decode(const DecodeArgs& a, hipStream_t s);
+
 }  // namespace zlng

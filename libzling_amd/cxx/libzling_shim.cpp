@@ -1,0 +1,199 @@
+// libzling_shim.cpp -- baidu::zling::{Encode, Decode} and the stdio helpers, implemented on the
+// C-ABI of include/zlng.h (HIP kernels in libzlng_hip.so).
+//
+// What is kept from the reference's block driver (src/libzling.cpp:174-291, 293-427) is its
+// OBSERVABLE protocol: OnInit before any I/O; blocks are read with a GetData loop until 16 MiB or
+// end of input; every block's bytes are pushed (PutData loop, short writes allowed) before that
+// block's OnProcess(raw block, size); OnDone on every exit path; -1 iff a stream reports an error.
+// What changes is the schedule: a batch of blocks is handed to the GPU at once so many 16 MiB
+// blocks are parsed concurrently; per_block_out_end lets the bytes and callbacks still be emitted
+// block by block in stream order.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "libzling.h"
+#include "zlng.h"
+
+namespace baidu {
+namespace zling {
+
+// ---- Inputter / Outputter helpers (src/libzling_utils.cpp:40-65) ---------------------------
+int Inputter::GetChar() {
+    unsigned char b = 0;
+    GetData(&b, 1);
+    return b;
+}
+uint32_t Inputter::GetUInt32() {
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++) v = v << 8 | (uint32_t)GetChar();
+    return v;
+}
+int Outputter::PutChar(int v) {
+    unsigned char b = (unsigned char)v;
+    PutData(&b, 1);
+    return b;
+}
+uint32_t Outputter::PutUInt32(uint32_t v) {
+    for (int shift = 24; shift >= 0; shift -= 8) PutChar((int)(v >> shift & 0xFF));
+    return v;
+}
+
+// ---- stdio implementations (src/libzling_utils.cpp:67-92) -----------------------------------
+size_t FileInputter::GetData(unsigned char* buf, size_t len) {
+    size_t n = fread(buf, 1, len, fp_);
+    consumed_ += n;
+    return n;
+}
+bool FileInputter::IsEnd() {
+    int c = fgetc(fp_);
+    if (c == EOF) return true;
+    ungetc(c, fp_);
+    return false;
+}
+bool FileInputter::IsErr() { return ferror(fp_) != 0; }
+size_t FileInputter::GetInputSize() { return consumed_; }
+
+size_t FileOutputter::PutData(unsigned char* buf, size_t len) {
+    size_t n = fwrite(buf, 1, len, fp_);
+    produced_ += n;
+    return n;
+}
+bool FileOutputter::IsErr() { return ferror(fp_) != 0; }
+size_t FileOutputter::GetOutputSize() { return produced_; }
+
+namespace {
+
+const size_t kBlock = ZLNG_BLOCK_SIZE;
+
+// Blocks handed to the GPU per call.  More blocks in flight = more parallel parse chains; the
+// batch is bounded so memory stays bounded for unbounded streams.  ZLNG_BATCH_BLOCKS overrides.
+int batch_blocks() {
+    const char* e = getenv("ZLNG_BATCH_BLOCKS");
+    int n = e ? atoi(e) : 64;
+    return n < 1 ? 1 : (n > 4096 ? 4096 : n);
+}
+int pick_device() {
+    const char* e = getenv("ZLNG_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+struct CtxGuard {
+    zlng_ctx* c;
+    explicit CtxGuard(zlng_ctx* p) : c(p) {}
+    ~CtxGuard() { zlng_destroy(c); }
+};
+
+zlng_ctx* make_ctx(int level, bool encode, int blocks) {
+    int err = 0;
+    zlng_ctx* c = zlng_create(pick_device(), level, encode ? 1 : 0, blocks, &err);
+    if (!c) {
+        if (err == ZLNG_E_NOMEM) throw std::bad_alloc();
+        throw std::runtime_error(std::string("zling: no gfx950 device (") + zlng_strerror(err) + ")");
+    }
+    return c;
+}
+
+bool push_all(Outputter* out, unsigned char* p, size_t n) {       // src/libzling.cpp:273-276
+    for (size_t off = 0; off < n && !out->IsErr();) off += out->PutData(p + off, n - off);
+    return !out->IsErr();
+}
+
+}  // namespace
+
+int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int level) {
+    if (handler) {
+        handler->SetInputterOutputter(inputter, outputter, true);
+        handler->OnInit();
+    }
+    bool bad_level = level < 0 || level > 4;     // the reference would emit a corrupt stream
+    if (!bad_level) {
+        const int nb = batch_blocks();
+        CtxGuard ctx(make_ctx(level, true, nb));
+        std::vector<unsigned char> in((size_t)nb * kBlock), out(zlng_encode_bound((size_t)nb * kBlock));
+        std::vector<size_t> ilen((size_t)nb), ends((size_t)nb);
+        bool failed = false;
+        while (!failed && !inputter->IsEnd() && !inputter->IsErr()) {
+            // fill up to nb blocks exactly as the reference fills one (src/libzling.cpp:193-196)
+            int have = 0;
+            size_t total = 0;
+            while (have < nb && !inputter->IsEnd() && !inputter->IsErr()) {
+                size_t got = 0;
+                unsigned char* dst = in.data() + (size_t)have * kBlock;
+                while (!inputter->IsEnd() && !inputter->IsErr() && got < kBlock) {
+                    got += inputter->GetData(dst + got, kBlock - got);
+                    if (inputter->IsErr()) break;
+                }
+                if (inputter->IsErr()) { failed = true; break; }
+                ilen[(size_t)have] = got;
+                total += got;
+                have++;
+                if (got < kBlock) break;          // a short block can only be the stream's last
+            }
+            if (failed || have == 0) break;
+            size_t produced = 0;
+            int rc = zlng_encode_blocks(ctx.c, in.data(), total, out.data(), out.size(), &produced, ends.data());
+            if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
+            if (rc != ZLNG_OK) throw std::runtime_error(std::string("baidu::zling::Encode(): ") + zlng_strerror(rc));
+            size_t prev = 0;
+            for (int b = 0; b < have; b++) {      // bytes, then the callback, block by block
+                if (!push_all(outputter, out.data() + prev, ends[(size_t)b] - prev)) { failed = true; break; }
+                prev = ends[(size_t)b];
+                if (handler) handler->OnProcess(in.data() + (size_t)b * kBlock, ilen[(size_t)b]);
+            }
+        }
+    }
+    if (handler) handler->OnDone();
+    return (bad_level || inputter->IsErr() || outputter->IsErr()) ? -1 : 0;
+}
+
+int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
+    if (handler) {
+        handler->SetInputterOutputter(inputter, outputter, false);
+        handler->OnInit();
+    }
+    {
+        const int nb = std::min(batch_blocks(), 16);
+        CtxGuard ctx(make_ctx(0, false, nb));
+        // A .zlng stream has no index: the compressed bytes are pulled in chunks, whole blocks found in
+        // the accumulated prefix are decoded, the unconsumed tail is kept for the next round.
+        std::vector<unsigned char> z, raw((size_t)nb * kBlock);
+        std::vector<size_t> ends((size_t)nb);
+        const size_t chunk = 8u << 20;
+        bool failed = false, eof = false;
+        while (!failed) {
+            if (!eof) {
+                size_t old = z.size();
+                z.resize(old + chunk);
+                size_t got = 0;
+                while (got < chunk && !inputter->IsEnd() && !inputter->IsErr()) got += inputter->GetData(z.data() + old + got, chunk - got);
+                z.resize(old + got);
+                if (inputter->IsErr()) { failed = true; break; }
+                eof = inputter->IsEnd();
+            }
+            if (z.empty()) break;
+            size_t used = 0, produced = 0;
+            int rc = zlng_decode_blocks(ctx.c, z.data(), z.size(), &used, raw.data(), raw.size(), &produced, ends.data());
+            if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
+            if (rc == ZLNG_E_TRUNC && !eof) { continue; }            // need more bytes for the next block
+            if (rc != ZLNG_OK) throw std::runtime_error(zlng_strerror(rc));
+            size_t prev = 0;
+            for (size_t b = 0; b < ends.size() && prev < produced; b++) {   // src/libzling.cpp:412-419
+                if (!push_all(outputter, raw.data() + prev, ends[b] - prev)) { failed = true; break; }
+                if (handler) handler->OnProcess(raw.data() + prev, ends[b] - prev);
+                prev = ends[b];
+            }
+            z.erase(z.begin(), z.begin() + (long)used);
+            if (used == 0 && eof) {
+                if (!z.empty()) throw std::runtime_error(zlng_strerror(ZLNG_E_TRUNC));
+                break;
+            }
+            if (z.empty() && eof) break;
+        }
+    }
+    if (handler) handler->OnDone();
+    return (inputter->IsErr() || outputter->IsErr()) ? -1 : 0;
+}
+
+}  // namespace zling
+}  // namespace baidu

@@ -1,0 +1,48 @@
+"""The drop-in C++ API (libzling_amd.so over the C-ABI) exercised through tools/zling_demo, the
+counterpart of the reference's demo/zling.cpp used by its own fuzz test (test/fuzzy/libzling_fuzzy.py:20-42)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "tools", "zling_demo")
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    from libzling_amd import build
+    build.build_all()
+    assert os.path.exists(DEMO)
+
+
+@pytest.mark.parametrize("name,level", [("text_64k", 0), ("text_64k", 4), ("runs_ab", 2), ("text_1", 0), ("text_0", 0)])
+def test_cli_encode_matches_golden_and_roundtrips(tmp_path, name, level):
+    src = os.path.join(G, name + ".bin")
+    want = np.fromfile(os.path.join(G, "%s.e%d.zlng" % (name, level)), dtype=np.uint8)
+    enc, dec = str(tmp_path / "o.zlng"), str(tmp_path / "o.bin")
+    subprocess.check_call([DEMO, "e%d" % level, src, enc])
+    assert np.array_equal(np.fromfile(enc, dtype=np.uint8), want)
+    subprocess.check_call([DEMO, "d", enc, dec])
+    assert np.array_equal(np.fromfile(dec, dtype=np.uint8), np.fromfile(src, dtype=np.uint8))
+
+
+def test_cli_streams_through_pipes_multiblock(tmp_path, oracle):
+    x = corpus.get("carry_2blk")
+    p = subprocess.run([DEMO, "e0"], input=x.tobytes(), stdout=subprocess.PIPE, check=True)
+    z = np.frombuffer(p.stdout, dtype=np.uint8)
+    assert np.array_equal(z, oracle.encode(x, 0))
+    q = subprocess.run([DEMO, "d"], input=p.stdout, stdout=subprocess.PIPE, check=True)
+    assert q.stdout == x.tobytes()
+
+
+def test_cli_rejects_corrupt_stream(tmp_path):
+    bad = tmp_path / "bad.zlng"
+    bad.write_bytes(bytes([9, 1, 2, 3]))
+    r = subprocess.run([DEMO, "d", str(bad), str(tmp_path / "x")], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"invalid encflag" in r.stderr

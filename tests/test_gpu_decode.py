@@ -1,0 +1,82 @@
+"""GPU parity of the decode path (K7 frame walk, K8 Huffman decode, K9 ROLZ+MTF replay) through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def zl():
+    import libzling_amd as zl
+    assert zl.lib().zlng_device_count() >= 1, "no gfx950 device visible"
+    return zl
+
+
+def gpu_decode(zl, z, cap, nb=2):
+    with zl.Stream(0, 0, False, nb) as s:
+        return s.decode(z, cap)
+
+
+@pytest.mark.parametrize("name", sorted(corpus.SMALL))
+def test_small_golden_streams_decode(zl, name):
+    x = np.fromfile(os.path.join(G, name + ".bin"), dtype=np.uint8)
+    for lv in (0, 2, 4):
+        z = np.fromfile(os.path.join(G, "%s.e%d.zlng" % (name, lv)), dtype=np.uint8)
+        back = gpu_decode(zl, z, max(x.size, 1))
+        assert np.array_equal(back, x), (name, lv)
+
+
+@pytest.mark.parametrize("name", ["text_700k", "rand_1m", "zeros_1m", "abc_1m", "skew_400k", "mixed_e4"])
+def test_large_reference_streams_decode(zl, oracle, name):
+    x = corpus.get(name)
+    for lv in (0, 4):
+        z = oracle.encode(x, lv)                 # pinned to the reference's bytes by test_oracle_golden.py
+        assert np.array_equal(gpu_decode(zl, z, x.size), x), (name, lv)
+
+
+def test_two_block_stream_carries_mtf(zl, oracle):
+    x = corpus.get("carry_2blk")
+    z = oracle.encode(x, 0)
+    assert np.array_equal(gpu_decode(zl, z, x.size, nb=2), x)
+
+
+def test_gpu_roundtrip_of_gpu_stream(zl):
+    from oracle_py import textgen
+    x = np.concatenate([textgen(900_000, 81), np.zeros(70_000, np.uint8), textgen(200_000, 82)])
+    z = zl.encode(x, 3)
+    assert np.array_equal(gpu_decode(zl, z, x.size), x)
+
+
+def test_corrupt_streams_map_to_reference_errors(zl, oracle):
+    x = corpus.get("text_64k")
+    z = oracle.encode(x, 0)
+
+    def code_of(bad):
+        with pytest.raises(zl.ZlngError) as e:
+            gpu_decode(zl, bad, x.size)
+        return e.value.code
+
+    bad = z.copy(); bad[0] = 7
+    assert code_of(bad) == -10                                   # "invalid encflag."
+    bad = z.copy(); bad[5:9] = [0, 0x10, 0, 0]
+    assert code_of(bad) == -11                                   # "invalid block size."
+    bad = z.copy(); bad[1:5] = [0, 0, 0, 9]
+    assert code_of(bad) == -15                                   # "lzdecode failed."
+    assert code_of(z[:-1]) == -16                                # block not closed: truncated
+    assert "invalid encflag" in zl.strerror(-10) and "lzdecode failed" in zl.strerror(-15)
+    # corrupt bits inside the payload either still decode to a stream of the right length that
+    # differs, or raise one of the stream errors -- never crash, never hang
+    rng = np.random.Generator(np.random.PCG64(3))
+    for _ in range(20):
+        bad = z.copy()
+        bad[int(rng.integers(300, z.size - 2))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            back = gpu_decode(zl, bad, x.size)
+            assert back.size <= x.size
+        except zl.ZlngError as e:
+            assert e.code in (-12, -13, -14, -15, -1)
