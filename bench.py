@@ -85,12 +85,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     # ---- this rank's share of the workload
+    from libzling_amd import sharding
     single = args.shard == "single-stream" and world > 1
     if single:
-        per = ((args.size + BLOCK - 1) // BLOCK) * BLOCK           # inner ranks hold whole blocks
-        total = args.size * world
-        n = per if rank < world - 1 else total - per * (world - 1)
-        first_chunk = rank * (per // BLOCK)
+        off, n = sharding.plan(args.size * world, world, per_rank_bytes=args.size)[rank]
+        first_chunk = off // BLOCK
     else:
         n = args.size
         first_chunk = rank * 4096                                   # distinct stream per rank
@@ -107,18 +106,12 @@ def main():
 
     def step():
         if single:
-            stream.parse_device(d_in.data_ptr(), n)
-            if rank == 0:
-                stream.set_state(init_state, init_level)
-            else:
-                dist.recv(d_state, src=rank - 1)
-                torch.cuda.synchronize()
-                stream.set_state_device(d_state.data_ptr(), args.level)
-            m = stream.finish_device(d_out.data_ptr(), cap)
-            if rank < world - 1:
-                stream.get_state_device(d_state.data_ptr())
-                dist.send(d_state, dst=rank + 1)
-            return m
+            return sharding.run_handoff(
+                stream, rank, world, dist, d_state, init_state, init_level, args.level,
+                parse=lambda: stream.parse_device(d_in.data_ptr(), n),
+                finish=lambda: stream.finish_device(d_out.data_ptr(), cap),
+                state_to_buf=lambda b: stream.get_state_device(b.data_ptr()),
+                buf_to_state=lambda b, lv: (torch.cuda.synchronize(), stream.set_state_device(b.data_ptr(), lv)))
         stream.set_state(init_state, init_level)                   # a fresh stream every step
         return stream.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
 

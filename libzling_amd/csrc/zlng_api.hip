@@ -61,6 +61,11 @@ struct zlng_ctx {
     uint8_t*  d_mtf = nullptr;        // live MTF tables (65,536 B)
     uint8_t*  d_mtf_saved = nullptr;  // tables at call entry (restored when a level re-run is needed)
     unsigned long long* d_dbg = nullptr;  // parser phase counters (ZLNG_PROFILE=1)
+    uint32_t* d_tile_base = nullptr;
+    uint32_t* d_tile_hist = nullptr;
+    uint32_t* d_ctx_total = nullptr;
+    uint32_t* d_ctx_off = nullptr;
+    uint8_t*  d_lit_byte = nullptr;
     // decode pools
     DecSub*   d_subs = nullptr;
     DecBlock* d_blocks = nullptr;
@@ -166,7 +171,7 @@ int run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, bool
 }
 
 int run_back(zlng_ctx* c, uint32_t nb, uint8_t* d_out, size_t out_cap) {
-    MtfArgs ma{c->d_tok, c->d_ntok, nb, c->d_mtf};
+    MtfArgs ma{c->d_tok, c->d_ntok, nb, c->d_mtf, c->d_tile_base, c->d_tile_hist, c->d_ctx_total, c->d_ctx_off, c->d_lit_byte};
     launch_mtf_rank(ma, c->stream);
     timer_mark(c, "mtf_rank");
     HuffArgs ha{c->d_tok, c->d_cuts, c->d_nsub, nb, c->d_freq, c->d_lens, c->d_codes, c->d_olen,
@@ -318,7 +323,9 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
             (rc = dev_alloc(c, &c->d_freq, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_lens, nsubs * kNsymAll)) ||
             (rc = dev_alloc(c, &c->d_codes, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_olen, nsubs)) ||
             (rc = dev_alloc(c, &c->d_sub_off, nsubs)) || (rc = dev_alloc(c, &c->d_blk_end, nb)) ||
-            (rc = dev_alloc(c, &c->d_summary, 8)))
+            (rc = dev_alloc(c, &c->d_summary, 8)) || (rc = dev_alloc(c, &c->d_tile_base, nb + 1)) ||
+            (rc = dev_alloc(c, &c->d_tile_hist, nb * (kTokCap / 4096) * 256)) || (rc = dev_alloc(c, &c->d_ctx_total, 256)) ||
+            (rc = dev_alloc(c, &c->d_ctx_off, 256)) || (rc = dev_alloc(c, &c->d_lit_byte, nb * kTokCap)))
             return fail(rc);
         c->h_sched.resize(nsubs);
         c->h_nsub.resize(nb);
@@ -342,7 +349,8 @@ void zlng_destroy(zlng_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
-                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring};
+                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring, c->d_tile_base, c->d_tile_hist,
+                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);

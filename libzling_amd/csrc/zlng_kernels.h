@@ -26,6 +26,11 @@ struct MtfArgs {
     const uint32_t* ntok;      // NB
     uint32_t        nblocks;
     uint8_t*        state;     // 256 x 256 MTF tables, context-major; updated in place
+    uint32_t*       tile_base; // [NB + 1] dense tile number of each block's first tile
+    uint32_t*       tile_hist; // [tiles][256] literals per context per tile -> exclusive prefix per context
+    uint32_t*       ctx_total; // [256]
+    uint32_t*       ctx_off;   // [256] start of each context's dense run
+    uint8_t*        lit_byte;  // dense literal bytes, context-major, stream order inside a context; ranks in place
 };
 void launch_mtf_rank(const MtfArgs& a, hipStream_t s);
 
