@@ -202,37 +202,56 @@ void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t 
 //           dependent HBM round trips of a token are paid once per window instead of once per token,
 //           and independent loads (ring offset + suffix of a node, the lazy probes' hash heads,
 //           16-byte compare chunks) are issued together to shorten the chain.
-//  phase 2  (wave-uniform walk, mostly SALU) the true token chain inside the window is resolved
-//           serially: P -> P+len -> ...  Each accepted start performs the dictionary insert.  A
-//           lane's speculative result is used only if nothing it READ was written by an earlier
-//           accepted start of the same round:
-//             - its hash slot (ctx, hash13)        -> (keymask & accepted) != 0
-//             - a ring slot it visited: slots are handed out consecutively per context, so only a
-//               visited node within 64 slots ahead of the round's starting head can be hit; such
-//               lanes (rare) are flagged `ring risk` and always take the exact path
-//           (the lazy probes have their own read sets, checked against accepted starts INCLUDING
-//           the lane's own insert -- a probe may hit the entry just inserted, src/libzling_lz.cpp:271).
-//           Otherwise the token is re-evaluated by match_exact() against the now-current state,
-//           so the result is the reference's in every case.
+//  phase 2  resolves the true token chain inside the window.  A lone wavefront issues about one
+//           instruction per 4 cycles, so nothing per-token is done in scalar code except a
+//           pointer chase over the per-lane token lengths (P -> P+len -> ...); everything else is
+//           evaluated for all 64 lanes at once:
+//             * a lane's speculative match is valid unless an EARLIER ACCEPTED start of this round
+//               wrote something it read: its hash slot (same (ctx, hash13): `keymask & acc`) or a
+//               ring slot it visited (slots are handed out consecutively per context, so the slots
+//               written this round are head0+1 .. head0+k: `dmin <= k`); the lazy probes have their
+//               own read sets, checked against accepted starts INCLUDING the lane's own insert
+//               (a probe may hit the entry just inserted, src/libzling_lz.cpp:271);
+//             * a non-match lane is a literal unless the word MRU can possibly hit: the two MRU
+//               slots of its context only ever hold their value at the start of the segment or
+//               the word of an in-window token boundary with the same key, so lanes whose word
+//               matches neither are literals without looking at MRU state;
+//           the clean prefix of the chase is then COMMITTED by vector code -- dictionary inserts,
+//           token words (coalesced), and the word-MRU events of all its token boundaries (an exact
+//           lane-parallel evaluation of the 2-slot push rules) -- and only the first "problem"
+//           token (conflict, possible word hit) is replayed by exact scalar code (match_exact and
+//           the serial MRU logic of EncodeImpl), after which the chase resumes behind it.
+//           The result is the reference's in every case.
 //
-// A single wavefront issues about one instruction per 4 cycles, so the serial walk is written to
-// be short: per-lane facts are packed into a few words that the walk pulls with v_readlane and
-// tests with scalar mask arithmetic.  Same-key / same-context lane sets come from two LDS bitmask
-// tables (64-bit LDS atomic OR, one bit per lane); the word MRU (1 KiB) and the per-context ring
-// heads live in LDS; tokens are staged in a VGPR and stored 64 at a time.
+// MRU bookkeeping convention: the push that EncodeImpl performs after a token (src/libzling_lz.cpp
+// :163-166, :181-182, :190-191) is attached to the NEXT token start ("boundary event" with key
+// buf[e-3] and word buf[e-2..e-1], conditional after a match, unconditional after a literal or a
+// 257 word, absent after a 256 word) and applied when that lane is processed; the type of the
+// last token is carried across rounds, and dropped at a sub-block end like the reference's MRU.
 constexpr int kKeyTab = 4096;                        // 64-bit lane masks, indexed by a hash of (ctx, hash13)
+constexpr int kEvTab = 4096;                         // 64-bit lane masks, indexed by a hash of (key byte, word)
 
 __device__ __forceinline__ uint32_t key_ix(uint32_t ctx, uint32_t hc) { return (hc ^ (ctx * 0x9E5u)) & (kKeyTab - 1); }
+__device__ __forceinline__ uint32_t ev_ix(uint32_t key, uint32_t word) { return (word ^ (word >> 7) ^ (key * 0x2D1u)) & (kEvTab - 1); }
 __device__ __forceinline__ uint32_t ring_dist(uint32_t node, uint32_t head0) { return (node - head0 - 1u) & (kRing - 1); }
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int lane) {
+    return (unsigned long long)rl((uint32_t)(v >> 32), lane) << 32 | rl((uint32_t)v, lane);
+}
+__device__ __forceinline__ uint32_t ufl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t hash_of(uint32_t w) { return w + ((w >> 16) & 0xFF) * 137u + (w >> 24) * 13337u; }
+__device__ __forceinline__ int top_bit(unsigned long long m) { return 63 - __clzll((long long)m); }     // m != 0
 
 // packed speculative result of one lane
 constexpr uint32_t kSpLenMask = 0x1FF;               // bits 0..8  maxlen (3 = none)
 constexpr int      kSpNodeShift = 9;                 // bits 9..20 maxnode
 constexpr uint32_t kSpVeto1 = 1u << 21, kSpVeto2 = 1u << 22, kSpCanMatch = 1u << 23;
-constexpr uint32_t kSpRisk = 1u << 24, kSpRisk1 = 1u << 25, kSpRisk2 = 1u << 26;   // read set near the ring head
-constexpr uint32_t kRiskDist = 64;                   // a round hands out < 64 slots per context
+constexpr uint32_t kSpRisk1 = 1u << 25, kSpRisk2 = 1u << 26;   // lazy read set near the ring head
+constexpr int      kMinRestart = 12;                 // restart a round at a conflict only if it resolved >= 12 positions
+constexpr uint32_t kRiskDist = 64;                   // a round hands out <= 64 slots per context
+
+// token kinds (also the "previous token" kind carried to the next boundary)
+constexpr uint32_t kTyNone = 0, kTyLit = 1, kTyW0 = 2, kTyW1 = 3, kTyMatch = 4;
 
 struct Quad { uint32_t a, b, c, d; };
 __device__ __forceinline__ Quad ld128u(const uint8_t* p) { Quad q; __builtin_memcpy(&q, p, 16); return q; }
@@ -261,6 +280,8 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
     __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
     __shared__ unsigned long long keytab[kKeyTab];
     __shared__ unsigned long long ctxtab[256];
+    __shared__ unsigned long long evtab[kEvTab];
+    __shared__ unsigned long long ektab[256];
     const uint32_t blk = blockIdx.x;
     const size_t base = (size_t)blk * kBlockIn;
     if (base >= a.in_len) return;
@@ -271,48 +292,55 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
     SubCut* cuts = a.cuts + (size_t)blk * kMaxSub;
     const int lane = threadIdx.x;
     const unsigned long long lane_bit = 1ull << lane;
+    const unsigned long long below = lane_bit - 1ull, beloweq = below | lane_bit;
 
-    for (int i = lane; i < 256; i += 64) { heads[i] = 0; ctxtab[i] = 0; }
-    for (int i = lane; i < kKeyTab; i += 64) keytab[i] = 0;
+    for (int i = lane; i < 256; i += 64) { heads[i] = 0; ctxtab[i] = 0; ektab[i] = 0; }
+    for (int i = lane; i < kKeyTab; i += 64) { keytab[i] = 0; evtab[i] = 0; }
     __syncthreads();
 
-    uint32_t tokv = 0, nt = 0;
+    uint32_t nt = 0;
     int q = 0, nsub = 0;
-    unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_lredo = 0, n_cand = 0;
+    unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
     const bool prof = a.dbg != nullptr;
-    auto emit = [&](uint32_t v) {
-        tokv = lane == (int)(nt & 63) ? v : tokv;
-        nt++;
-        if ((nt & 63) == 0) tok[nt - 64 + lane] = tokv;
-    };
 
     while (q < ilen) {                               // ---- one sub-block (one EncodeImpl call)
         const LevelCfg cfg = level_cfg(a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)]);
         const uint32_t tok_begin = nt;
         int opos = 0;
-        bool pend = false;                           // match-end MRU update waiting for next round's bytes
+        uint32_t prevty = kTyNone;                   // kind of the token that ended at q (none: MRU starts empty)
         for (int i = lane; i < 256; i += 64) mru[i] = 0;
         __syncthreads();
         if (q == 0) {                                // src/libzling_lz.cpp:150-151
-            emit((uint32_t)buf[0] | kTokRawCtx << 16); q = 1; opos = 1;
-            if (ilen > 1) { emit((uint32_t)buf[1] | kTokRawCtx << 16); q = 2; opos = 2; }
+            if (lane == 0) tok[nt] = (uint32_t)buf[0] | kTokRawCtx << 16;
+            nt++; q = 1; opos = 1;
+            if (ilen > 1) { if (lane == 0) tok[nt] = (uint32_t)buf[1] | kTokRawCtx << 16; nt++; q = 2; opos = 2; }
         }
 
         while (q < ilen && opos + 1 < kSubSyms) {    // ---- one round
+            // round state is wave-uniform by construction; pin it to scalar registers
+            q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
             const int P = q;
             unsigned long long t0 = 0, t1 = 0, t2 = 0;
             if (prof) t0 = __builtin_readcyclecounter();
             // ---------------- phase 1: speculative evaluation of position P + lane
             const int pos = P + lane;
+            const bool live = pos < ilen;
             const bool canm = pos + kSentinel < ilen;
             uint32_t wp, w4 = 0;
             if (pos >= 4) wp = ld32u(buf + pos - 4); else wp = ld32u(buf) << (8 * (4 - pos));
-            if (pos < ilen) w4 = ld32u(buf + pos);
+            if (live) w4 = ld32u(buf + pos);
             const uint32_t ctx = wp >> 24;
             const uint32_t h = hash_of(w4);
             const uint32_t hc = h % kHashSlots, chk = (h / kHashSlots) & 255u;
             const uint32_t kix = key_ix(ctx, hc);
-            uint32_t sp = kMatchMin - 1, node0 = 65535, head0 = 0;
+            // MRU operands: as a token start (check key / word) and as a token boundary (event key / word)
+            const uint32_t b_m3 = (wp >> 8) & 0xFF, b_m2 = (wp >> 16) & 0xFF, b_0 = w4 & 0xFF, b_1 = (w4 >> 8) & 0xFF;
+            const uint32_t cw = b_0 << 8 | b_1;                    // check: mru[ctx] vs (b0, b1)
+            const uint32_t ek = b_m3, ew = b_m2 << 8 | ctx;        // event at this boundary: mru[b-3] <- (b-2, b-1)
+            const uint32_t evix = ev_ix(ek, ew), chix = ev_ix(ctx, cw);
+            if (live) { atomicOr(&evtab[evix], lane_bit); atomicOr(&ektab[ek], lane_bit); }
+
+            uint32_t sp = kMatchMin - 1, node0 = 65535, head0 = 0, dmin = kRing - 1;
             uint32_t lkix1 = 0, lkix2 = 0, lctx1 = 0, lctx2 = 0;
             bool lz1 = false, lz2 = false;
             if (canm) {
@@ -338,7 +366,7 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
                 uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
 
                 int maxlen = kMatchMin - 1;
-                uint32_t maxnode = 0, node = node0, dmin = kRing - 1;
+                uint32_t maxnode = 0, node = node0;
                 if (node != 65535) {
                     for (int i = 0; i < cfg.depth; i++) {
                         dmin = min(dmin, ring_dist(node, head0));
@@ -356,7 +384,6 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
                         node = nx; ov = nov; nx = nnx;
                     }
                 }
-                if (dmin < kRiskDist) sp |= kSpRisk;
                 sp = (sp & ~kSpLenMask) | (uint32_t)maxlen | maxnode << kSpNodeShift;
                 if (maxlen >= kMatchMin && maxlen < kLazyLimit) {
                     const int m = maxlen - 3;
@@ -400,121 +427,174 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
             }
             if (prof) t1 = __builtin_readcyclecounter();
             __syncthreads();                         // all lane bits are in the tables
-            unsigned long long keymask = 0, ctxmask = 0, lkey1 = 0, lkey2 = 0;
+            unsigned long long keymask = 0, ctxmask = 0, lkey = 0;
             if (canm) { keymask = keytab[kix]; ctxmask = ctxtab[ctx]; }
             // a lazy probe is invalidated by an accepted insert with its key, or -- if it walked near the
             // ring head -- by any accepted insert into its bucket
-            if (lz1) lkey1 = keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
-            if (lz2) lkey2 = keytab[lkix2] | ((sp & kSpRisk2) ? ctxtab[lctx2] : 0ull);
+            if (lz1) lkey |= keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
+            if (lz2) lkey |= keytab[lkix2] | ((sp & kSpRisk2) ? ctxtab[lctx2] : 0ull);
+            const unsigned long long hitmask = live ? evtab[chix] : 0ull;   // boundaries whose (key, word) may equal my check
+            const unsigned long long samekey = live ? ektab[ek] : 0ull;     // boundaries with my event key
             __syncthreads();
             if (canm) { keytab[kix] = 0; ctxtab[ctx] = 0; }
-            const uint32_t km_lo = (uint32_t)keymask, km_hi = (uint32_t)(keymask >> 32);
-            const uint32_t cm_lo = (uint32_t)ctxmask, cm_hi = (uint32_t)(ctxmask >> 32);
-            const uint32_t l1_lo = (uint32_t)lkey1, l1_hi = (uint32_t)(lkey1 >> 32);
-            const uint32_t l2_lo = (uint32_t)lkey2, l2_hi = (uint32_t)(lkey2 >> 32);
-            // MRU operands of this position: as a token start (check key / literal event) and as a match end
-            const uint32_t b_m3 = (wp >> 8) & 0xFF, b_m2 = (wp >> 16) & 0xFF, b_m1 = wp >> 24, b_0 = w4 & 0xFF, b_1 = (w4 >> 8) & 0xFF;
-            const uint32_t x_chk = b_m1 | (b_0 << 8 | b_1) << 16;           // mru[b-1] vs word (b0, b1)
-            const uint32_t x_lit = b_m2 | (b_m1 << 8 | b_0) << 16;          // literal: mru[b-2] <- (b-1, b0)
-            const uint32_t x_end = b_m3 | (b_m2 << 8 | b_m1) << 16;         // match ending here: mru[b-3] <- (b-2, b-1)
+            if (live) { evtab[evix] = 0; ektab[ek] = 0; }
 
-            // ---------------- phase 2: resolve the token chain inside [P, P + 64)
+            // speculative token of this lane: match (if not vetoed by its speculative lazy probes) or literal
+            const uint32_t spec_len = sp & kSpLenMask;
+            const bool spec_veto = ((sp & kSpVeto1) != 0) || (cfg.lazy2 > 0 && (sp & kSpVeto2) != 0);
+            const bool spec_match = canm && spec_len >= (uint32_t)kMatchMin && !(spec_len < (uint32_t)kLazyLimit && spec_veto);
+            const uint32_t tlen = spec_match ? spec_len : 1u;
+            const unsigned long long match_lanes = __ballot(spec_match);
+
+            // ---------------- phase 2
             if (prof) { t2 = __builtin_readcyclecounter(); c_p1 += t1 - t0; c_mask += t2 - t1; n_round++; }
-            unsigned long long acc = 0;              // lanes whose position was an inserting token start
-            if (pend) {                              // match ended beyond the previous window
-                const uint32_t xe = rl(x_end, 0);
-                const uint32_t cu = xe & 0xFF, w = xe >> 16, m = mru[cu];
-                if ((m & 0xFFFF) != w) mru[cu] = (m << 16) | w;
-                pend = false;
-            }
-            while (q < P + 64 && q < ilen && opos + 1 < kSubSyms) {
+            unsigned long long acc = 0;              // accepted token starts of this round (committed or replayed)
+            const bool near_cut = opos + 2 * 64 + 4 >= kSubSyms;
+
+            // exact scalar replay of the token at q (wave-uniform): boundary event, match_exact / word MRU / literal
+            auto serial_token = [&](bool use_spec) {
                 const int sl = q - P;
-                const uint32_t spq = rl(sp, sl);
+                const uint32_t xk = rl(ek, sl), xw = rl(ew, sl);
+                // (LDS values are wave-uniform here; readfirstlane tells the compiler so, which keeps q / opos /
+                //  prevty and with them the whole round control flow in scalar registers)
+                if (prevty == kTyMatch) { const uint32_t m = ufl(mru[xk]); if ((m & 0xFFFF) != xw) mru[xk] = (m << 16) | xw; }
+                else if (prevty == kTyLit || prevty == kTyW1) { mru[xk] = (ufl(mru[xk]) << 16) | xw; }
                 bool is_match = false;
                 int mlen = 0, midx = 0;
+                const uint32_t spq = rl(sp, sl);
                 if (spq & kSpCanMatch) {
-                    const unsigned long long kmq = (unsigned long long)rl(km_hi, sl) << 32 | rl(km_lo, sl);
-                    const unsigned long long cmq = (unsigned long long)rl(cm_hi, sl) << 32 | rl(cm_lo, sl);
-                    const uint32_t head = (rl(head0, sl) + (uint32_t)__popcll(cmq & acc) + 1u) & (kRing - 1);
-                    const bool dirty = (spq & kSpRisk) || (kmq & acc);
-                    acc |= 1ull << sl;
-                    if (prof) { n_cand++; if (dirty) n_redo++; }
-                    if (dirty) {
-                        int mi = 0, ml = 0;
-                        const bool hit = match_exact(dict, buf, q, cfg, head, lane == 0, mi, ml);
-                        is_match = __builtin_amdgcn_readfirstlane((int)hit) != 0;
-                        mlen = __builtin_amdgcn_readfirstlane(ml);
-                        midx = __builtin_amdgcn_readfirstlane(mi);
-                    } else {
-                        if (lane == sl) {            // the insert (src/libzling_lz.cpp:227-230)
+                    const uint32_t head = (rl(head0, sl) + (uint32_t)__popcll(rl64(ctxmask, sl) & acc) + 1u) & (kRing - 1);
+                    if (use_spec) {                  // speculation validated by the caller: insert + speculative result
+                        if (lane == sl) {
                             Bucket B(dict, ctx);
                             B.suffix[head] = (uint16_t)node0;
                             B.offset[head] = (uint32_t)pos | chk << 24;
                             B.hash[hc] = (uint16_t)head;
                         }
-                        const int maxlen = (int)(spq & kSpLenMask);
-                        if (maxlen >= kMatchMin) {
-                            bool veto = false;
-                            if (maxlen < kLazyLimit && cfg.lazy1 > 0) {
-                                const unsigned long long l1q = (unsigned long long)rl(l1_hi, sl) << 32 | rl(l1_lo, sl);
-                                if (l1q & acc) {
-                                    if (prof) n_lredo++;
-                                    veto = __builtin_amdgcn_readfirstlane((int)lazy_probe(dict, buf, q + 1, maxlen, cfg.lazy1)) != 0;
-                                } else veto = (spq & kSpVeto1) != 0;
-                                if (!veto && cfg.lazy2 > 0) {
-                                    const unsigned long long l2q = (unsigned long long)rl(l2_hi, sl) << 32 | rl(l2_lo, sl);
-                                    if (l2q & acc) veto = __builtin_amdgcn_readfirstlane((int)lazy_probe(dict, buf, q + 2, maxlen, cfg.lazy2)) != 0;
-                                    else veto = (spq & kSpVeto2) != 0;
-                                }
-                            }
-                            if (!veto) {
-                                is_match = true;
-                                mlen = maxlen;
-                                midx = (int)((head - ((spq >> kSpNodeShift) & (kRing - 1))) & (kRing - 1));
-                            }
-                        }
-                    }
-                }
-                if (is_match) {                      // src/libzling_lz.cpp:160-167
-                    emit((uint32_t)(258 + mlen - kMatchMin) | (uint32_t)midx << 16);
-                    opos += 2;
-                    q += mlen;
-                    if (q - P < 64) {
-                        const uint32_t xe = rl(x_end, q - P);
-                        const uint32_t cu = xe & 0xFF, w = xe >> 16, m = mru[cu];
-                        if ((m & 0xFFFF) != w) mru[cu] = (m << 16) | w;
+                        is_match = ((match_lanes >> sl) & 1ull) != 0;
+                        mlen = (int)(spq & kSpLenMask);
+                        midx = (int)((head - ((spq >> kSpNodeShift) & (kRing - 1))) & (kRing - 1));
                     } else {
-                        pend = true;
+                        int mi = 0, ml = 0;
+                        const bool hit = match_exact(dict, buf, q, cfg, head, lane == 0, mi, ml);
+                        is_match = __builtin_amdgcn_readfirstlane((int)hit) != 0;
+                        mlen = __builtin_amdgcn_readfirstlane(ml);
+                        midx = __builtin_amdgcn_readfirstlane(mi);
                     }
-                    continue;
                 }
-                const uint32_t xc = rl(x_chk, sl);
-                const uint32_t cq = xc & 0xFF, w = xc >> 16;
-                if (q + 1 < ilen) {                  // src/libzling_lz.cpp:172-185
-                    const uint32_t m = mru[cq];
-                    if ((m & 0xFFFF) == w) { emit(256); opos++; q += 2; continue; }
-                    if ((m >> 16) == w) { emit(257); opos++; q += 2; mru[cq] = (m << 16) | w; continue; }
+                acc |= 1ull << sl;
+                uint32_t word;
+                if (is_match) {                      // src/libzling_lz.cpp:160-167
+                    word = (uint32_t)(258 + mlen - kMatchMin) | (uint32_t)midx << 16;
+                    opos += 2; q += mlen; prevty = kTyMatch;
+                } else {
+                    const uint32_t cq = rl(ctx, sl), w = rl(cw, sl);
+                    const uint32_t m = ufl(mru[cq]);
+                    if (q + 1 < ilen && (m & 0xFFFF) == w) { word = 256; opos++; q += 2; prevty = kTyW0; }          // :172-177
+                    else if (q + 1 < ilen && (m >> 16) == w) { word = 257; opos++; q += 2; prevty = kTyW1; }         // :178-184
+                    else { word = (w >> 8) | cq << 16; opos++; q++; prevty = kTyLit; }                              // :188-191 (raw; K2 ranks)
                 }
-                emit((w >> 8) | cq << 16);           // literal, raw (rank stage K2), src/libzling_lz.cpp:188-191
-                opos++;
-                q++;
-                const uint32_t xl = rl(x_lit, sl);
-                const uint32_t cu = xl & 0xFF;
-                mru[cu] = (mru[cu] << 16) | (xl >> 16);
+                if (lane == 0) tok[nt] = word;
+                nt++;
+            };
+
+            if (near_cut) {
+                // the sub-block is about to fill up (src/libzling_lz.cpp:153): replay token by token
+                while (q < P + 64 && q < ilen && opos + 1 < kSubSyms) serial_token(false);
+            } else {
+                unsigned long long seg = 0;
+                while (q < P + 64 && q < ilen) {
+                    if (prof) n_seg++;
+                    // ---- chase: token starts reachable from q under the speculative lengths.  Chains from
+                    // different starts merge, so after a replayed token the previous chase is usually still good.
+                    q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
+                    seg = (unsigned long long)ufl((uint32_t)(seg >> 32)) << 32 | ufl((uint32_t)seg);
+                    int s = q - P;
+                    unsigned long long tc = 0;
+                    if (prof) tc = __builtin_readcyclecounter();
+                    if ((seg >> s) & 1ull) seg &= ~((1ull << s) - 1ull);
+                    else { seg = 0; while (s < 64 && P + s < ilen) { seg |= 1ull << s; s += (int)rl(tlen, s); } }
+                    if (prof) c_chase += __builtin_readcyclecounter() - tc;
+                    // ---- validate every lane against (acc | seg); only lanes of seg matter
+                    const unsigned long long all = acc | seg;
+                    const uint32_t k = (uint32_t)__popcll(ctxmask & all & below);
+                    const bool dirty = canm && (((keymask & all & below) != 0) || dmin <= k);
+                    const bool ldirty = spec_len >= (uint32_t)kMatchMin && (lkey & all & beloweq) != 0;
+                    const uint32_t m0 = mru[ctx];
+                    const bool poss = !spec_match && pos + 1 < ilen &&
+                                      ((m0 & 0xFFFF) == cw || (m0 >> 16) == cw || (hitmask & all & beloweq) != 0);
+                    const unsigned long long prob = seg & __ballot(dirty || ldirty || poss);
+                    const int f = prob ? (int)__builtin_ctzll(prob) : 64;
+                    const unsigned long long com = f >= 64 ? seg : (seg & ((1ull << f) - 1ull));
+                    if (com) {
+                        const bool mine = (com & lane_bit) != 0;
+                        // ---- MRU events of the committed boundaries (lane-parallel 2-slot push rules)
+                        const int first = (int)__builtin_ctzll(com);
+                        const unsigned long long prev_m = com & below;            // earlier committed lanes
+                        const int pj = prev_m ? top_bit(prev_m) : 0;
+                        const uint32_t pty = prev_m ? (((match_lanes >> pj) & 1ull) ? kTyMatch : kTyLit) : prevty;
+                        const bool is_ev = mine && (pty == kTyMatch || pty == kTyLit || pty == kTyW1);
+                        const unsigned long long evs = __ballot(is_ev);
+                        const uint32_t m0e = mru[ek];
+                        const unsigned long long before_k = samekey & evs & below;
+                        const int pe = before_k ? top_bit(before_k) : 0;
+                        const uint32_t ew_pe = (uint32_t)__shfl((int)ew, pe);
+                        const uint32_t s0b = before_k ? ew_pe : (m0e & 0xFFFF);    // slot 0 just before my event
+                        const bool eff = is_ev && (pty != kTyMatch || ew != s0b);
+                        const unsigned long long effs = __ballot(eff);
+                        const unsigned long long upto = samekey & effs & beloweq;
+                        const int es = upto ? top_bit(upto) : 0;
+                        const uint32_t s0b_es = (uint32_t)__shfl((int)s0b, es);
+                        const bool last_of_key = is_ev && (samekey & evs & ~beloweq) == 0;
+                        if (last_of_key) mru[ek] = ew | (upto ? s0b_es : (m0e >> 16)) << 16;
+                        (void)first;
+                        // ---- dictionary inserts (src/libzling_lz.cpp:227-230) and token words
+                        const uint32_t head = (head0 + k + 1u) & (kRing - 1);
+                        if (mine) {
+                            uint32_t word;
+                            if (canm) {
+                                Bucket B(dict, ctx);
+                                B.suffix[head] = (uint16_t)node0;
+                                B.offset[head] = (uint32_t)pos | chk << 24;
+                                B.hash[hc] = (uint16_t)head;
+                            }
+                            if (spec_match) word = (258u + spec_len - kMatchMin) | ((head - ((sp >> kSpNodeShift) & (kRing - 1))) & (kRing - 1)) << 16;
+                            else word = b_0 | ctx << 16;
+                            tok[nt + (uint32_t)__popcll(com & below)] = word;
+                        }
+                        const int lastl = top_bit(com);
+                        const bool last_match = ((match_lanes >> lastl) & 1ull) != 0;
+                        nt += (uint32_t)__popcll(com);
+                        opos += __popcll(com) + __popcll(com & match_lanes);
+                        acc |= com;
+                        q = P + lastl + (int)rl(tlen, lastl);
+                        prevty = last_match ? kTyMatch : kTyLit;
+                    }
+                    if (f < 64) {
+                        const bool conflict = rl((dirty || ldirty) ? 1u : 0u, f) != 0;
+                        unsigned long long ts = 0;
+                        if (prof) { if (conflict) n_redo++; else n_poss++; ts = __builtin_readcyclecounter(); }
+                        // A conflict with an earlier start of this round disappears when the round restarts at
+                        // that token (its speculation then sees every committed insert); only a token that opens
+                        // the round and still conflicts (with its own insert / ring slot) needs the exact replay.
+                        if (conflict && f >= kMinRestart) break;
+                        serial_token(!conflict);
+                        if (prof) c_ser += __builtin_readcyclecounter() - ts;
+                    }
+                }
             }
             if (prof) c_p2 += __builtin_readcyclecounter() - t2;
             // publish the ring heads advanced by this round (every accepted lane of a context writes the same value)
-            if (acc & lane_bit) heads[ctx] = (uint16_t)((head0 + (uint32_t)__popcll(ctxmask & acc)) & (kRing - 1));
+            if (canm && (acc & lane_bit)) heads[ctx] = (uint16_t)((head0 + (uint32_t)__popcll(ctxmask & acc)) & (kRing - 1));
             __syncthreads();
         }
         if (nsub < kMaxSub && lane == 0) cuts[nsub] = SubCut{tok_begin, nt, (uint32_t)q, (uint32_t)opos};
         nsub++;
     }
-    if (lane < (int)(nt & 63)) tok[(nt & ~63u) + lane] = tokv;
     if (lane == 0) { a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt; }
     if (prof && lane == 0) {
         unsigned long long* d = a.dbg + (size_t)blk * 16;
-        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_cand; d[6] = n_redo; d[7] = n_lredo;
+        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase;
     }
 }
 
