@@ -42,6 +42,20 @@ __device__ __forceinline__ void wrl(uint32_t& v, uint32_t val, uint32_t lane) {
     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane));
 }
 
+// per-lane select by a wave-uniform 64-bit lane mask held in an SGPR pair: lane l gets (mask bit l) ? b : a.
+// (Plain C++ makes the compiler rebuild the mask test per lane with v_and + v_cmp_u64; this is one instruction.
+//  The mask comes from v_cmp / s_lshr_b64; gfx9 owes no wait states for a VALU reading such an SGPR as a constant.)
+__device__ __forceinline__ uint32_t sel(uint32_t a, uint32_t b, uint64_t mask) {
+    uint32_t r;
+    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ uint32_t cvec(uint32_t uniform) {           // wave-uniform scalar as a VGPR operand
+    uint32_t r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(uniform));
+    return r;
+}
+
 __device__ __forceinline__ bool is_literal(uint32_t v) { return (v & 0xFF00u) == 0 && (v >> 16) < 256u; }
 
 // Number of tiles before block b, in stream order (tiny; one lane).
@@ -142,19 +156,47 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
 // t[r] holds table[64 r + l].  rank = position of c (compare + ballot, no index[] array);
 // swap with the entry at mtfnext[rank] = two v_writelane.  Ranks < 64 -- almost every literal of
 // text -- touch t0 only.
+// One literal.  Ranks 0..20 (n = rank - 1: swap with the left neighbour; the bulk of text literals)
+// never leave the vector unit: with vcc = lanes whose entry differs from c,
+//     t0[l] = vcc ? t0[l] : t0[l-1]          one DPP select (wave_shr:1; lane 0 keeps its value, so rank 0 is a no-op)
+//     t0[l] = hit[l+1] ? c : t0[l]           one select with the hit mask shifted right by one
+// The update is applied speculatively and undone when the hit was not in lanes 0..20, so the table's
+// dependency chain never waits for the scalar rank, which is only needed for the output lane.
+// Hazards inside the block (gfx9): a DPP source must be >= 2 wait states behind its VALU writer -- the
+// previous writer of t0 is the second select of the previous step, followed by s_ff1, v_writelane and this
+// step's v_cmp / s_not / s_lshr; SALU reads of the VALU-written vcc are interlocked; the v_writelane lane
+// select is an immediate.
+#define ZLNG_MTF_FAST(K, M0)                                                                        \
+    asm volatile(                                                                                  \
+        "v_mov_b32 %[cv], %[c]\n\t"                                                                \
+        "v_cmp_ne_u32_e32 vcc, %[cv], %[t0]\n\t"                                                   \
+        "s_not_b64 %[m0], vcc\n\t"                                                                 \
+        "s_lshr_b64 %[m1], %[m0], 1\n\t"                                                           \
+        "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"     \
+        "v_cndmask_b32_e64 %[t0], %[t0], %[cv], %[m1]\n\t"                                         \
+        "s_ff1_i32_b64 %[i], %[m0]\n\t"                                                            \
+        : [t0] "+v"(t0), [m0] "=&s"(M0), [m1] "=&s"(m1_), [i] "=&s"(i), [cv] "=&v"(cv)             \
+        : [c] "s"(c)                                                                               \
+        : "vcc")
+
 #define ZLNG_MTF_STEP(K)                                                                           \
     {                                                                                              \
         const uint32_t c = rdl(v, (K));                                                            \
-        uint32_t i;                                                                                \
-        const uint64_t m0 = __ballot(t0 == c);                                                     \
-        if (__builtin_expect(m0 != 0, 1)) {                                                        \
-            i = (uint32_t)__builtin_ctzll(m0);                                                     \
-            const uint32_t nx = (i * 62263u) >> 16;                                                \
-            const uint32_t d = rdl(t0, nx);                                                        \
-            wrl(t0, d, i);                                                                         \
-            wrl(t0, c, nx);                                                                        \
-        } else {                                                                                   \
-            i = slow_step(c);                                                                      \
+        uint64_t m0, m1_;                                                                          \
+        uint32_t i, cv;                                                                            \
+        ZLNG_MTF_FAST(K, m0);                                                                      \
+        if (__builtin_expect(i > 20u, 0)) {         /* s_ff1 gives 0xFFFFFFFF when there is no hit */ \
+            if (m0) {                       /* rank 21..63: undo the neighbour swap, do the real one */ \
+                const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t0, 0x130, 0xf, 0xf, true); /* wave_shl:1 */ \
+                t0 = sel(t0, up, m1_);                                                             \
+                t0 = sel(t0, cv, m0);                                                              \
+                const uint32_t nx = (i * 62263u) >> 16;                                            \
+                const uint32_t d = rdl(t0, nx);                                                    \
+                wrl(t0, d, i);                                                                     \
+                wrl(t0, c, nx);                                                                    \
+            } else {                                                                               \
+                i = slow_step(c);                                                                  \
+            }                                                                                      \
         }                                                                                          \
         RANKSTORE(i, K);                                                                           \
     }
