@@ -445,6 +445,26 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
             const bool spec_match = canm && spec_len >= (uint32_t)kMatchMin && !(spec_len < (uint32_t)kLazyLimit && spec_veto);
             const uint32_t tlen = spec_match ? spec_len : 1u;
             const unsigned long long match_lanes = __ballot(spec_match);
+            // four-token jumps for the chase: next start after 4 tokens and the starts passed on the way
+            // (two doubling steps over ds_bpermute; a lone wave pays ~100 cycles per scalar hop otherwise)
+            uint32_t hop_next;
+            unsigned long long hop_mask;
+            {
+                const uint32_t n1 = live ? min((uint32_t)lane + tlen, 64u) : 64u;
+                const unsigned long long m1 = live ? lane_bit : 0ull;
+                const bool v1 = n1 < 64u;
+                const uint32_t n2g = (uint32_t)__shfl((int)n1, (int)(n1 & 63u));
+                const unsigned long long m1g = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(m1 >> 32), (int)(n1 & 63u)) << 32 |
+                                               (uint32_t)__shfl((int)(uint32_t)m1, (int)(n1 & 63u));
+                const uint32_t n2 = v1 ? n2g : 64u;
+                const unsigned long long m2 = m1 | (v1 ? m1g : 0ull);
+                const bool v2 = n2 < 64u;
+                const uint32_t n4g = (uint32_t)__shfl((int)n2, (int)(n2 & 63u));
+                const unsigned long long m2g = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(m2 >> 32), (int)(n2 & 63u)) << 32 |
+                                               (uint32_t)__shfl((int)(uint32_t)m2, (int)(n2 & 63u));
+                hop_next = v2 ? n4g : 64u;
+                hop_mask = m2 | (v2 ? m2g : 0ull);
+            }
 
             // ---------------- phase 2
             if (prof) { t2 = __builtin_readcyclecounter(); c_p1 += t1 - t0; c_mask += t2 - t1; n_round++; }
@@ -513,7 +533,7 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
                     unsigned long long tc = 0;
                     if (prof) tc = __builtin_readcyclecounter();
                     if ((seg >> s) & 1ull) seg &= ~((1ull << s) - 1ull);
-                    else { seg = 0; while (s < 64 && P + s < ilen) { seg |= 1ull << s; s += (int)rl(tlen, s); } }
+                    else { seg = 0; while (s < 64) { seg |= rl64(hop_mask, s); s = (int)rl(hop_next, s); } }
                     if (prof) c_chase += __builtin_readcyclecounter() - tc;
                     // ---- validate every lane against (acc | seg); only lanes of seg matter
                     const unsigned long long all = acc | seg;
