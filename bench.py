@@ -149,6 +149,19 @@ def main():
         dom_ms = stage.get(dom, 0.0) if dom else 0.0
         alg_bytes = float(n) + float(out_len)                       # every input byte read once,
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0   # every .zlng byte written once
+        # HBM traffic of the dominant kernel per launch from the committed PMC passes (profiles/), when they
+        # were taken on this same workload; rocprofv3 cannot run inside this process
+        traffic = None
+        tsrc = None
+        kmap = {"rolz_parse": "k_rolz_parse_wave", "mtf_rank": "k_mtf_dense", "huff_pack": "k_pack"}
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            wl = pj["workload"]
+            if world == 1 and wl["bytes"] == args.size and wl["level"] == args.level and source == "synthetic":
+                traffic = pj["kernels"][kmap[dom]]["hbm_bytes_corrected"]
+                tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, (2*FETCH+WRITE)*1024)"
+        except Exception:
+            pass
         res = {
             "metric": METRIC, "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -160,7 +173,8 @@ def main():
                        "input_bytes_total": int(total_in), "zlng_bytes_total": int(total_out)},
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 3),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None},
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": tsrc,
+                         "algorithmic_bytes": int(alg_bytes)},
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
         }
         if not args.no_cpu_baseline and world == 1:
