@@ -198,41 +198,57 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
             for (uint32_t i = lane; i < 256; i += 64) mru[i] = 0;
             __syncthreads();
             uint32_t ti = 0;
+            // Every value that steers the loop is wave-uniform (all lanes replay the same token); readfirstlane
+            // says so to the compiler, which keeps opos / ti / the branch conditions in scalar registers.
+            // Token words are pulled 64 at a time into a register window (lane l holds word base + l).
+            auto ufl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+            uint32_t twin = lane < nt ? tok[lane] : 0u, tbase = 0;
+            auto next_token = [&]() -> uint32_t {
+                if (ti - tbase >= 64u) { tbase += 64u; twin = tbase + lane < nt ? tok[tbase + lane] : 0u; }
+                return (uint32_t)__builtin_amdgcn_readlane((int)twin, (int)(ti++ - tbase));
+            };
             // first two bytes of a block are raw (src/libzling_lz.cpp:327-328)
             while (opos < 2 && ti < nt) {
-                const uint32_t v = tok[ti++];
+                const uint32_t v = next_token();
                 if ((v & 0xFFFF) >= 256 || opos + 1 > sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
                 if (lane == 0) out[opos] = (uint8_t)v;
                 opos++;
             }
+            // the last three bytes written are tracked in scalars (b3 = out[opos-3], b2, b1 = out[opos-1]);
+            // only a match has to look them up again
+            uint32_t b1 = 0, b2 = 0, b3 = 0;
+            if (opos >= 1) b1 = ufl(out[opos - 1]);
+            if (opos >= 2) b2 = ufl(out[opos - 2]);
+            if (opos >= 3) b3 = ufl(out[opos - 3]);
             while (ti < nt && !err) {
-                const uint32_t v = tok[ti++], sym = v & 0xFFFF;
-                const uint32_t c1 = out[opos - 1];                    // order-1 context
+                const uint32_t v = next_token(), sym = v & 0xFFFF;
+                const uint32_t c1 = b1;                               // order-1 context
                 // GetMatchAndUpdate: every token inserts its start position (src/libzling_lz.cpp:388-399)
-                const uint32_t head = (heads[c1] + 1u) & (kRing - 1);
+                const uint32_t head = (ufl(heads[c1]) + 1u) & (kRing - 1);
                 uint32_t* r = ring + c1 * kRing;
-                const uint32_t src = sym >= 258 ? r[(head - (v >> 16)) & (kRing - 1)] : 0;
                 if (lane == 0) { heads[c1] = (uint16_t)head; r[head] = opos; }
                 if (sym < 256) {                                      // literal: ZlingMTFDecoder::Decode :122-126
                     if (opos + 1 > sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
                     uint8_t* t = mtf + c1 * 256;
                     const uint32_t nx = mtf_next(sym);
-                    const uint8_t cc = t[sym], dd = t[nx];
-                    if (lane == 0) { t[sym] = dd; t[nx] = cc; out[opos] = cc; }
+                    const uint32_t cc = ufl(t[sym]), dd = ufl(t[nx]);
+                    if (lane == 0) { t[sym] = (uint8_t)dd; t[nx] = (uint8_t)cc; out[opos] = (uint8_t)cc; }
                     opos++;
-                    const uint32_t cu = out[opos - 3];
-                    if (lane == 0) mru[cu] = (mru[cu] << 16) | (c1 << 8 | cc);
+                    b3 = b2; b2 = b1; b1 = cc;
+                    if (lane == 0) mru[b3] = (mru[b3] << 16) | (b2 << 8 | b1);
                 } else if (sym < 258) {                               // word MRU slot 0 / 1
                     if (opos + 2 > sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
-                    const uint32_t m = mru[c1];
+                    const uint32_t m = ufl(mru[c1]);
                     const uint32_t w = sym == 256 ? (m & 0xFFFF) : (m >> 16);
                     if (lane == 0) {
                         out[opos] = (uint8_t)(w >> 8); out[opos + 1] = (uint8_t)w;
                         if (sym == 257) mru[c1] = (m << 16) | w;
                     }
                     opos += 2;
+                    b3 = b1; b2 = w >> 8; b1 = w & 0xFF;
                 } else {                                              // match
                     const uint32_t mlen = sym - 258 + kMatchMin;
+                    const uint32_t src = ufl(r[(head - (v >> 16)) & (kRing - 1)]);
                     if (opos + mlen > sb.encpos || src >= opos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
                     const uint32_t dist = opos - src;
                     if (dist >= 64 || dist >= mlen) {
@@ -241,9 +257,10 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
                         for (uint32_t j = lane; j < mlen; j += 64) out[opos + j] = out[src + j % dist];
                     }
                     opos += mlen;
-                    const uint32_t cu = out[opos - 3], w = (uint32_t)out[opos - 2] << 8 | out[opos - 1];
-                    const uint32_t m = mru[cu];
-                    if (lane == 0 && (m & 0xFFFF) != w) mru[cu] = (m << 16) | w;
+                    b3 = ufl(out[opos - 3]); b2 = ufl(out[opos - 2]); b1 = ufl(out[opos - 1]);
+                    const uint32_t w = b2 << 8 | b1;
+                    const uint32_t m = ufl(mru[b3]);
+                    if (lane == 0 && (m & 0xFFFF) != w) mru[b3] = (m << 16) | w;
                 }
             }
             if (!err && opos != sb.encpos) err = (uint32_t)(-ZLNG_DEC_E_LZ);   // src/libzling_lz.cpp:371-373
