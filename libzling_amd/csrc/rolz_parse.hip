@@ -275,13 +275,117 @@ __device__ __forceinline__ int common_len_q(const uint8_t* a, const uint8_t* b, 
     return n;
 }
 
-__global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
+// Speculative evaluation of one position as a token start (phase 1 of the parser, also run ahead of
+// it by the prefetch wavefront): hash head, <= depth chain nodes with exact LCP, lazy probes.
+// Read-only on the dictionary.  `dmin` = ring distance (ahead of the context's head) of the nearest
+// visited node; lz*/lkix*/lctx* describe the lazy probes' read sets.
+struct Spec {
+    uint32_t sp, node0, head0, dmin;
+    uint32_t lkix1, lkix2, lctx1, lctx2;
+    bool lz1, lz2;
+};
+
+__device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
+                                          const LevelCfg cfg, uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
+    uint32_t sp = (kMatchMin - 1) | kSpCanMatch, dmin = kRing - 1;
+    const uint32_t head0 = heads[ctx];
+    const Quad qa = ld128u(buf + pos);               // bytes pos .. pos+15 (pos+275 < ilen)
+    // lazy keys are pure functions of the input: start their chains together with the main one
+    const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
+    const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
+    Bucket B(dict, ctx), B1(dict, lctx1), B2(dict, lctx2);
+    const uint32_t lhead1 = heads[lctx1], lhead2 = heads[lctx2];
+    const uint32_t node0 = B.hash[hc];
+    uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
+    uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
+    // second hop of all three chains
+    uint32_t ov = B.offset[node0 & (kRing - 1)];
+    uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
+
+    int maxlen = kMatchMin - 1;
+    uint32_t maxnode = 0, node = node0;
+    if (node != 65535) {
+        for (int i = 0; i < cfg.depth; i++) {
+            dmin = min(dmin, ring_dist(node, head0));
+            const uint32_t off = ov & 0xFFFFFF;
+            // next hop's ring entry is fetched together with this hop's compare bytes
+            const uint32_t nov = B.offset[nx & (kRing - 1)];
+            const uint32_t nnx = B.suffix[nx & (kRing - 1)];
+            if ((ov >> 24) == chk) {
+                const int len = common_len_q(buf + pos, buf + off, qa);
+                if (len > maxlen) { maxnode = node; maxlen = len; if (maxlen == kMatchMax) break; }
+            }
+            if (nx == 65535) break;
+            dmin = min(dmin, ring_dist(nx, head0));
+            if (off <= (nov & 0xFFFFFF)) break;
+            node = nx; ov = nov; nx = nnx;
+        }
+    }
+    sp = (sp & ~kSpLenMask) | (uint32_t)maxlen | maxnode << kSpNodeShift;
+    bool lz1 = false, lz2 = false;
+    if (maxlen >= kMatchMin && maxlen < kLazyLimit) {
+        const int m = maxlen - 3;
+        if (want1) {                                 // MatchLazy(pos + 1), src/libzling_lz.cpp:291-316
+            lz1 = true;
+            uint32_t ld = kRing - 1, n1 = ln1;
+            if (n1 != 65535) {
+                const uint32_t probe = ld32u(buf + pos + 1 + m);
+                for (int i = 0; i < cfg.lazy1; i++) {
+                    ld = min(ld, ring_dist(n1, lhead1));
+                    const uint32_t off = lov1 & 0xFFFFFF;
+                    if (probe == ld32u(buf + off + m)) { sp |= kSpVeto1; break; }
+                    n1 = B1.suffix[n1];
+                    if (n1 == 65535) break;
+                    ld = min(ld, ring_dist(n1, lhead1));
+                    lov1 = B1.offset[n1];
+                    if (off <= (lov1 & 0xFFFFFF)) break;
+                }
+            }
+            if (ld < kRiskDist) sp |= kSpRisk1;
+        }
+        if (want2) {                                 // MatchLazy(pos + 2)
+            lz2 = true;
+            uint32_t ld = kRing - 1, n2 = ln2;
+            if (n2 != 65535) {
+                const uint32_t probe = ld32u(buf + pos + 2 + m);
+                for (int i = 0; i < cfg.lazy2; i++) {
+                    ld = min(ld, ring_dist(n2, lhead2));
+                    const uint32_t off = lov2 & 0xFFFFFF;
+                    if (probe == ld32u(buf + off + m)) { sp |= kSpVeto2; break; }
+                    n2 = B2.suffix[n2];
+                    if (n2 == 65535) break;
+                    ld = min(ld, ring_dist(n2, lhead2));
+                    lov2 = B2.offset[n2];
+                    if (off <= (lov2 & 0xFFFFFF)) break;
+                }
+            }
+            if (ld < kRiskDist) sp |= kSpRisk2;
+        }
+    }
+    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
+    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = key_ix(lctx2, hh2); S.lctx1 = lctx1; S.lctx2 = lctx2;
+    S.lz1 = lz1; S.lz2 = lz2;
+}
+
+// Ordering point for LDS traffic inside ONE wavefront (program order is execution order for a wave's LDS
+// operations; this only stops the compiler from moving accesses across it).  The parser's workgroup also
+// holds a prefetch wavefront that never joins a barrier, so the main wavefront must not use s_barrier.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     __shared__ uint16_t heads[256];
     __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
     __shared__ unsigned long long keytab[kKeyTab];
     __shared__ unsigned long long ctxtab[256];
     __shared__ unsigned long long evtab[kEvTab];
     __shared__ unsigned long long ektab[256];
+    __shared__ int pf_pos, pf_level, pf_done;        // round start / level / end flag published for the prefetch wave
     const uint32_t blk = blockIdx.x;
     const size_t base = (size_t)blk * kBlockIn;
     if (base >= a.in_len) return;
@@ -290,26 +394,56 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
     uint8_t* dict = a.dict + (size_t)blk * kDictBytes;
     uint32_t* tok = a.tok + (size_t)blk * kTokCap;
     SubCut* cuts = a.cuts + (size_t)blk * kMaxSub;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const unsigned long long lane_bit = 1ull << lane;
     const unsigned long long below = lane_bit - 1ull, beloweq = below | lane_bit;
 
-    for (int i = lane; i < 256; i += 64) { heads[i] = 0; ctxtab[i] = 0; ektab[i] = 0; }
-    for (int i = lane; i < kKeyTab; i += 64) { keytab[i] = 0; evtab[i] = 0; }
-    __syncthreads();
+    if (wave == 0) {
+        for (int i = lane; i < 256; i += 64) { heads[i] = 0; ctxtab[i] = 0; ektab[i] = 0; }
+        for (int i = lane; i < kKeyTab; i += 64) { keytab[i] = 0; evtab[i] = 0; }
+        if (lane == 0) { pf_pos = 0; pf_level = a.lvl_sched[blk * kMaxSub]; pf_done = 0; }
+    }
+    __syncthreads();                                 // the only workgroup barrier: wave 1 never joins another one
+
+    if (wave == 1) {
+        // ---- prefetch wavefront: runs the same speculative loads for the next window(s), results discarded.
+        // It only warms L2/L1 for the dependent chain (hash head -> ring entry -> source bytes) that bounds
+        // phase 1; correctness never depends on it (no LDS/global writes, benign race on pf_pos).
+        int done_to = 0;
+        while (true) {
+            const int P = __atomic_load_n(&pf_pos, __ATOMIC_RELAXED);
+            if (__atomic_load_n(&pf_done, __ATOMIC_RELAXED)) break;
+            int start = P + 64 > done_to ? P + 64 : done_to;
+            if (start >= P + 64 + 128 || start >= ilen) { __builtin_amdgcn_s_sleep(16); continue; }
+            const LevelCfg pcfg = level_cfg(__atomic_load_n(&pf_level, __ATOMIC_RELAXED));
+            const int pos = start + lane;
+            if (pos >= 4 && pos + kSentinel < ilen) {
+                const uint32_t wpp = ld32u(buf + pos - 4), w4p = ld32u(buf + pos);
+                const uint32_t hp = hash_of(w4p);
+                Spec S;
+                speculate(S, dict, buf, heads, pos, pcfg, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
+            }
+            done_to = start + 64;
+        }
+        return;
+    }
 
     uint32_t nt = 0;
     int q = 0, nsub = 0;
     unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
+    unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0;
     const bool prof = a.dbg != nullptr;
 
     while (q < ilen) {                               // ---- one sub-block (one EncodeImpl call)
         const LevelCfg cfg = level_cfg(a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)]);
+        if (lane == 0) __atomic_store_n(&pf_level, (int)a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)], __ATOMIC_RELAXED);
         const uint32_t tok_begin = nt;
         int opos = 0;
         uint32_t prevty = kTyNone;                   // kind of the token that ended at q (none: MRU starts empty)
         for (int i = lane; i < 256; i += 64) mru[i] = 0;
-        __syncthreads();
+        wsync();
         if (q == 0) {                                // src/libzling_lz.cpp:150-151
             if (lane == 0) tok[nt] = (uint32_t)buf[0] | kTokRawCtx << 16;
             nt++; q = 1; opos = 1;
@@ -320,6 +454,7 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
             // round state is wave-uniform by construction; pin it to scalar registers
             q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
             const int P = q;
+            if (lane == 0) __atomic_store_n(&pf_pos, P, __ATOMIC_RELAXED);
             unsigned long long t0 = 0, t1 = 0, t2 = 0;
             if (prof) t0 = __builtin_readcyclecounter();
             // ---------------- phase 1: speculative evaluation of position P + lane
@@ -340,93 +475,19 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
             const uint32_t evix = ev_ix(ek, ew), chix = ev_ix(ctx, cw);
             if (live) { atomicOr(&evtab[evix], lane_bit); atomicOr(&ektab[ek], lane_bit); }
 
-            uint32_t sp = kMatchMin - 1, node0 = 65535, head0 = 0, dmin = kRing - 1;
-            uint32_t lkix1 = 0, lkix2 = 0, lctx1 = 0, lctx2 = 0;
-            bool lz1 = false, lz2 = false;
+            Spec S;
+            S.sp = kMatchMin - 1; S.node0 = 65535; S.head0 = 0; S.dmin = kRing - 1;
+            S.lkix1 = S.lkix2 = S.lctx1 = S.lctx2 = 0; S.lz1 = S.lz2 = false;
             if (canm) {
-                sp |= kSpCanMatch;
                 atomicOr(&keytab[kix], lane_bit);
                 atomicOr(&ctxtab[ctx], lane_bit);
-                head0 = heads[ctx];
-                const Quad qa = ld128u(buf + pos);               // bytes pos .. pos+15 (pos+275 < ilen)
-                // lazy keys are pure functions of the input: start their chains together with the main one
-                const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
-                lctx1 = w4 & 0xFF; lctx2 = (w4 >> 8) & 0xFF;
-                const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
-                const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
-                lkix1 = key_ix(lctx1, hh1); lkix2 = key_ix(lctx2, hh2);
-                Bucket B(dict, ctx), B1(dict, lctx1), B2(dict, lctx2);
-                const uint32_t lhead1 = heads[lctx1], lhead2 = heads[lctx2];
-                node0 = B.hash[hc];
-                uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
-                uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
-                // second hop of all three chains
-                uint32_t ov = B.offset[node0 & (kRing - 1)];
-                uint32_t nx = B.suffix[node0 & (kRing - 1)];
-                uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
-
-                int maxlen = kMatchMin - 1;
-                uint32_t maxnode = 0, node = node0;
-                if (node != 65535) {
-                    for (int i = 0; i < cfg.depth; i++) {
-                        dmin = min(dmin, ring_dist(node, head0));
-                        const uint32_t off = ov & 0xFFFFFF;
-                        // next hop's ring entry is fetched together with this hop's compare bytes
-                        const uint32_t nov = B.offset[nx & (kRing - 1)];
-                        const uint32_t nnx = B.suffix[nx & (kRing - 1)];
-                        if ((ov >> 24) == chk) {
-                            const int len = common_len_q(buf + pos, buf + off, qa);
-                            if (len > maxlen) { maxnode = node; maxlen = len; if (maxlen == kMatchMax) break; }
-                        }
-                        if (nx == 65535) break;
-                        dmin = min(dmin, ring_dist(nx, head0));
-                        if (off <= (nov & 0xFFFFFF)) break;
-                        node = nx; ov = nov; nx = nnx;
-                    }
-                }
-                sp = (sp & ~kSpLenMask) | (uint32_t)maxlen | maxnode << kSpNodeShift;
-                if (maxlen >= kMatchMin && maxlen < kLazyLimit) {
-                    const int m = maxlen - 3;
-                    if (want1) {                                 // MatchLazy(pos + 1), src/libzling_lz.cpp:291-316
-                        lz1 = true;
-                        uint32_t ld = kRing - 1, n1 = ln1;
-                        if (n1 != 65535) {
-                            const uint32_t probe = ld32u(buf + pos + 1 + m);
-                            for (int i = 0; i < cfg.lazy1; i++) {
-                                ld = min(ld, ring_dist(n1, lhead1));
-                                const uint32_t off = lov1 & 0xFFFFFF;
-                                if (probe == ld32u(buf + off + m)) { sp |= kSpVeto1; break; }
-                                n1 = B1.suffix[n1];
-                                if (n1 == 65535) break;
-                                ld = min(ld, ring_dist(n1, lhead1));
-                                lov1 = B1.offset[n1];
-                                if (off <= (lov1 & 0xFFFFFF)) break;
-                            }
-                        }
-                        if (ld < kRiskDist) sp |= kSpRisk1;
-                    }
-                    if (want2) {                                 // MatchLazy(pos + 2)
-                        lz2 = true;
-                        uint32_t ld = kRing - 1, n2 = ln2;
-                        if (n2 != 65535) {
-                            const uint32_t probe = ld32u(buf + pos + 2 + m);
-                            for (int i = 0; i < cfg.lazy2; i++) {
-                                ld = min(ld, ring_dist(n2, lhead2));
-                                const uint32_t off = lov2 & 0xFFFFFF;
-                                if (probe == ld32u(buf + off + m)) { sp |= kSpVeto2; break; }
-                                n2 = B2.suffix[n2];
-                                if (n2 == 65535) break;
-                                ld = min(ld, ring_dist(n2, lhead2));
-                                lov2 = B2.offset[n2];
-                                if (off <= (lov2 & 0xFFFFFF)) break;
-                            }
-                        }
-                        if (ld < kRiskDist) sp |= kSpRisk2;
-                    }
-                }
+                speculate(S, dict, buf, heads, pos, cfg, w4, ctx, hc, chk);
             }
+            const uint32_t sp = S.sp, node0 = S.node0, head0 = S.head0, dmin = S.dmin;
+            const uint32_t lkix1 = S.lkix1, lkix2 = S.lkix2, lctx1 = S.lctx1, lctx2 = S.lctx2;
+            const bool lz1 = S.lz1, lz2 = S.lz2;
             if (prof) t1 = __builtin_readcyclecounter();
-            __syncthreads();                         // all lane bits are in the tables
+            wsync();                         // all lane bits are in the tables
             unsigned long long keymask = 0, ctxmask = 0, lkey = 0;
             if (canm) { keymask = keytab[kix]; ctxmask = ctxtab[ctx]; }
             // a lazy probe is invalidated by an accepted insert with its key, or -- if it walked near the
@@ -435,7 +496,7 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
             if (lz2) lkey |= keytab[lkix2] | ((sp & kSpRisk2) ? ctxtab[lctx2] : 0ull);
             const unsigned long long hitmask = live ? evtab[chix] : 0ull;   // boundaries whose (key, word) may equal my check
             const unsigned long long samekey = live ? ektab[ek] : 0ull;     // boundaries with my event key
-            __syncthreads();
+            wsync();
             if (canm) { keytab[kix] = 0; ctxtab[ctx] = 0; }
             if (live) { evtab[evix] = 0; ektab[ek] = 0; }
 
@@ -592,34 +653,48 @@ __global__ __launch_bounds__(64) void k_rolz_parse_wave(ParseArgs a) {
                     }
                     if (f < 64) {
                         const bool conflict = rl((dirty || ldirty) ? 1u : 0u, f) != 0;
+                        if (prof && conflict) {
+                            const uint32_t cls = rl((canm && (keymask & all & below) != 0 ? 1u : 0u) | (canm && dmin <= k ? 2u : 0u) | (ldirty ? 4u : 0u), f);
+                            if (cls & 1u) n_cA++; else if (cls & 2u) n_cB++; else n_cL++;
+                        }
+                        const int q_before = q; const uint32_t nt_before = nt;
                         unsigned long long ts = 0;
                         if (prof) { if (conflict) n_redo++; else n_poss++; ts = __builtin_readcyclecounter(); }
                         // A conflict with an earlier start of this round disappears when the round restarts at
                         // that token (its speculation then sees every committed insert); only a token that opens
                         // the round and still conflicts (with its own insert / ring slot) needs the exact replay.
-                        if (conflict && f >= kMinRestart) break;
+                        if (conflict && f >= a.min_restart) break;
                         serial_token(!conflict);
                         if (prof) c_ser += __builtin_readcyclecounter() - ts;
+                        if (prof && conflict) {      // did the exact replay agree with the speculation?
+                            n_replay++;
+                            const int sl2 = q_before - P;
+                            const uint32_t spec_adv = rl(tlen, sl2);
+                            const bool spec_m = ((match_lanes >> sl2) & 1ull) != 0;
+                            const bool got_m = prevty == kTyMatch;
+                            if (spec_m == got_m && (!got_m || (int)spec_adv == q - q_before)) n_same++;
+                            (void)nt_before;
+                        }
                     }
                 }
             }
             if (prof) c_p2 += __builtin_readcyclecounter() - t2;
             // publish the ring heads advanced by this round (every accepted lane of a context writes the same value)
             if (canm && (acc & lane_bit)) heads[ctx] = (uint16_t)((head0 + (uint32_t)__popcll(ctxmask & acc)) & (kRing - 1));
-            __syncthreads();
+            wsync();
         }
         if (nsub < kMaxSub && lane == 0) cuts[nsub] = SubCut{tok_begin, nt, (uint32_t)q, (uint32_t)opos};
         nsub++;
     }
-    if (lane == 0) { a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt; }
+    if (lane == 0) { __atomic_store_n(&pf_done, 1, __ATOMIC_RELAXED); a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt; }
     if (prof && lane == 0) {
         unsigned long long* d = a.dbg + (size_t)blk * 16;
-        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase;
+        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same;
     }
 }
 
 void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_rolz_parse_wave, dim3(nblocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_rolz_parse_wave, dim3(nblocks), dim3(128), 0, s, a);
 }
 
 }  // namespace zlng
