@@ -370,6 +370,85 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     S.lz1 = lz1; S.lz2 = lz2;
 }
 
+// Level-0 form of speculate() (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130): the same
+// semantics written as straight-line predicated code.  Every divergent if / break in the generic form costs
+// a handful of exec-mask instructions, and one wavefront issues an instruction only every few cycles, so on
+// the level the benchmark runs the generic form spends most of phase 1 on control flow rather than on the
+// five dependent memory round trips.  Only the >16-byte tail of a long match keeps a (wave-uniform) loop.
+__device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
+    const uint32_t x0 = qa.a ^ qb.a, x1 = qa.b ^ qb.b, x2 = qa.c ^ qb.c, x3 = qa.d ^ qb.d;
+    uint32_t len = x3 ? 12u + ((uint32_t)__ffs((int)x3) - 1u) / 8u : 16u;
+    len = x2 ? 8u + ((uint32_t)__ffs((int)x2) - 1u) / 8u : len;
+    len = x1 ? 4u + ((uint32_t)__ffs((int)x1) - 1u) / 8u : len;
+    return x0 ? 0u : len;
+}
+__device__ __forceinline__ uint32_t lcp_tail(const uint8_t* a, const uint8_t* b, bool active) {   // continue an LCP of 16
+    uint32_t n = 16;
+    while (__any(active)) {
+        if (active) {
+            if (n + 4 <= (uint32_t)kMatchMax) {
+                const uint32_t x = ld32u(a + n) ^ ld32u(b + n);
+                if (x) { n += ((uint32_t)__ffs((int)x) - 1u) / 8u; active = false; } else n += 4;
+            } else if (n < (uint32_t)kMatchMax && a[n] == b[n]) n++;
+            else active = false;
+        }
+    }
+    return n;
+}
+
+__device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
+                                             uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
+    const uint32_t head0 = heads[ctx];
+    const Quad qa = ld128u(buf + pos);
+    const uint32_t lctx1 = w4 & 0xFF;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    Bucket B(dict, ctx), B1(dict, lctx1);
+    const uint32_t lhead1 = heads[lctx1];
+    // round trip 1: both hash heads
+    const uint32_t node0 = B.hash[hc];
+    const uint32_t ln1 = B1.hash[hh1];
+    const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
+    // round trip 2: ring entries of the first nodes
+    const uint32_t ov0 = B.offset[node0 & (kRing - 1)];
+    const uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)];
+    const uint32_t off0 = ov0 & 0xFFFFFF;
+    // round trip 3: compare bytes of node 0 and the ring entry of node 1
+    const bool cmp0 = has0 && (ov0 >> 24) == chk;
+    const Quad q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
+    const uint32_t nov = B.offset[nx & (kRing - 1)];
+    uint32_t len0 = cmp0 ? lcp16(qa, q0) : 0u;
+    const bool long0 = cmp0 && len0 == 16u;
+    if (__any(long0)) { const uint32_t t = lcp_tail(buf + pos, buf + off0, long0); len0 = long0 ? t : len0; }
+    uint32_t maxlen = kMatchMin - 1, maxnode = 0;
+    if (len0 > maxlen) { maxlen = len0; maxnode = node0; }
+    // chain continues to node 1?  (src/libzling_lz.cpp:255-266)
+    const bool has1 = has0 && maxlen != (uint32_t)kMatchMax && nx != 65535u;
+    const uint32_t off1 = nov & 0xFFFFFF;
+    const bool go1 = has1 && !(off0 <= off1);
+    // round trip 4: compare bytes of node 1
+    const bool cmp1 = go1 && (nov >> 24) == chk;
+    const Quad q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
+    uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
+    const bool long1 = cmp1 && len1 == 16u;
+    if (__any(long1)) { const uint32_t t = lcp_tail(buf + pos, buf + off1, long1); len1 = long1 ? t : len1; }
+    if (len1 > maxlen) { maxlen = len1; maxnode = nx; }
+    uint32_t dmin = kRing - 1;
+    dmin = has0 ? min(dmin, ring_dist(node0, head0)) : dmin;
+    dmin = has1 ? min(dmin, ring_dist(nx, head0)) : dmin;          // its offset was read for the chain-end test
+    uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
+    // round trip 5: the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1)
+    const bool lz1 = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
+    const uint32_t m = lz1 ? maxlen - 3u : 0u;
+    const uint32_t probe = ld32u(buf + pos + 1 + m);
+    const uint32_t srcw = ld32u(buf + ((lz1 && hasl) ? (lov1 & 0xFFFFFF) + m : (uint32_t)pos));
+    if (lz1 && hasl && probe == srcw) sp |= kSpVeto1;
+    if (lz1 && hasl && ring_dist(ln1, lhead1) < kRiskDist) sp |= kSpRisk1;
+    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
+    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = 0; S.lctx1 = lctx1; S.lctx2 = 0;
+    S.lz1 = lz1; S.lz2 = false;
+}
+
 // Ordering point for LDS traffic inside ONE wavefront (program order is execution order for a wave's LDS
 // operations; this only stops the compiler from moving accesses across it).  The parser's workgroup also
 // holds a prefetch wavefront that never joins a barrier, so the main wavefront must not use s_barrier.
@@ -422,7 +501,8 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
                 const uint32_t wpp = ld32u(buf + pos - 4), w4p = ld32u(buf + pos);
                 const uint32_t hp = hash_of(w4p);
                 Spec S;
-                speculate(S, dict, buf, heads, pos, pcfg, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                if (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0) speculate_l0(S, dict, buf, heads, pos, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                else speculate(S, dict, buf, heads, pos, pcfg, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
             }
             done_to = start + 64;
@@ -439,6 +519,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     while (q < ilen) {                               // ---- one sub-block (one EncodeImpl call)
         const LevelCfg cfg = level_cfg(a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)]);
         if (lane == 0) __atomic_store_n(&pf_level, (int)a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)], __ATOMIC_RELAXED);
+        const bool level0 = cfg.depth == 2 && cfg.lazy1 == 1 && cfg.lazy2 == 0;
         const uint32_t tok_begin = nt;
         int opos = 0;
         uint32_t prevty = kTyNone;                   // kind of the token that ended at q (none: MRU starts empty)
@@ -481,7 +562,8 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             if (canm) {
                 atomicOr(&keytab[kix], lane_bit);
                 atomicOr(&ctxtab[ctx], lane_bit);
-                speculate(S, dict, buf, heads, pos, cfg, w4, ctx, hc, chk);
+                if (level0) speculate_l0(S, dict, buf, heads, pos, w4, ctx, hc, chk);
+                else speculate(S, dict, buf, heads, pos, cfg, w4, ctx, hc, chk);
             }
             const uint32_t sp = S.sp, node0 = S.node0, head0 = S.head0, dmin = S.dmin;
             const uint32_t lkix1 = S.lkix1, lkix2 = S.lkix2, lctx1 = S.lctx1, lctx2 = S.lctx2;
