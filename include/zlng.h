@@ -70,7 +70,8 @@ typedef struct zlng_ctx zlng_ctx;
 int zlng_device_count(void);
 
 /* Create a stream context on HIP device `device`.  level 0..4 (ignored for decode).
- * max_blocks = largest number of 16 MiB blocks a single call will pass (sizes the HBM pools).
+ * max_blocks = largest number of 16 MiB blocks a single call will pass (sizes the HBM pools; 1..240 --
+ * longer streams are fed in several calls, the stream state is carried by the context).
  * Returns NULL on error; *err (optional) receives the code. */
 zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int* err);
 void      zlng_destroy(zlng_ctx*);

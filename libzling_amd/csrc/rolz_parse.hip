@@ -285,96 +285,6 @@ struct Spec {
     bool lz1, lz2;
 };
 
-__device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
-                                          const LevelCfg cfg, uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
-    uint32_t sp = (kMatchMin - 1) | kSpCanMatch, dmin = kRing - 1;
-    const uint32_t head0 = heads[ctx];
-    const Quad qa = ld128u(buf + pos);               // bytes pos .. pos+15 (pos+275 < ilen)
-    // lazy keys are pure functions of the input: start their chains together with the main one
-    const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
-    const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
-    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
-    const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
-    Bucket B(dict, ctx), B1(dict, lctx1), B2(dict, lctx2);
-    const uint32_t lhead1 = heads[lctx1], lhead2 = heads[lctx2];
-    const uint32_t node0 = B.hash[hc];
-    uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
-    uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
-    // second hop of all three chains
-    uint32_t ov = B.offset[node0 & (kRing - 1)];
-    uint32_t nx = B.suffix[node0 & (kRing - 1)];
-    uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
-
-    int maxlen = kMatchMin - 1;
-    uint32_t maxnode = 0, node = node0;
-    if (node != 65535) {
-        for (int i = 0; i < cfg.depth; i++) {
-            dmin = min(dmin, ring_dist(node, head0));
-            const uint32_t off = ov & 0xFFFFFF;
-            // next hop's ring entry is fetched together with this hop's compare bytes
-            const uint32_t nov = B.offset[nx & (kRing - 1)];
-            const uint32_t nnx = B.suffix[nx & (kRing - 1)];
-            if ((ov >> 24) == chk) {
-                const int len = common_len_q(buf + pos, buf + off, qa);
-                if (len > maxlen) { maxnode = node; maxlen = len; if (maxlen == kMatchMax) break; }
-            }
-            if (nx == 65535) break;
-            dmin = min(dmin, ring_dist(nx, head0));
-            if (off <= (nov & 0xFFFFFF)) break;
-            node = nx; ov = nov; nx = nnx;
-        }
-    }
-    sp = (sp & ~kSpLenMask) | (uint32_t)maxlen | maxnode << kSpNodeShift;
-    bool lz1 = false, lz2 = false;
-    if (maxlen >= kMatchMin && maxlen < kLazyLimit) {
-        const int m = maxlen - 3;
-        if (want1) {                                 // MatchLazy(pos + 1), src/libzling_lz.cpp:291-316
-            lz1 = true;
-            uint32_t ld = kRing - 1, n1 = ln1;
-            if (n1 != 65535) {
-                const uint32_t probe = ld32u(buf + pos + 1 + m);
-                for (int i = 0; i < cfg.lazy1; i++) {
-                    ld = min(ld, ring_dist(n1, lhead1));
-                    const uint32_t off = lov1 & 0xFFFFFF;
-                    if (probe == ld32u(buf + off + m)) { sp |= kSpVeto1; break; }
-                    n1 = B1.suffix[n1];
-                    if (n1 == 65535) break;
-                    ld = min(ld, ring_dist(n1, lhead1));
-                    lov1 = B1.offset[n1];
-                    if (off <= (lov1 & 0xFFFFFF)) break;
-                }
-            }
-            if (ld < kRiskDist) sp |= kSpRisk1;
-        }
-        if (want2) {                                 // MatchLazy(pos + 2)
-            lz2 = true;
-            uint32_t ld = kRing - 1, n2 = ln2;
-            if (n2 != 65535) {
-                const uint32_t probe = ld32u(buf + pos + 2 + m);
-                for (int i = 0; i < cfg.lazy2; i++) {
-                    ld = min(ld, ring_dist(n2, lhead2));
-                    const uint32_t off = lov2 & 0xFFFFFF;
-                    if (probe == ld32u(buf + off + m)) { sp |= kSpVeto2; break; }
-                    n2 = B2.suffix[n2];
-                    if (n2 == 65535) break;
-                    ld = min(ld, ring_dist(n2, lhead2));
-                    lov2 = B2.offset[n2];
-                    if (off <= (lov2 & 0xFFFFFF)) break;
-                }
-            }
-            if (ld < kRiskDist) sp |= kSpRisk2;
-        }
-    }
-    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
-    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = key_ix(lctx2, hh2); S.lctx1 = lctx1; S.lctx2 = lctx2;
-    S.lz1 = lz1; S.lz2 = lz2;
-}
-
-// Level-0 form of speculate() (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130): the same
-// semantics written as straight-line predicated code.  Every divergent if / break in the generic form costs
-// a handful of exec-mask instructions, and one wavefront issues an instruction only every few cycles, so on
-// the level the benchmark runs the generic form spends most of phase 1 on control flow rather than on the
-// five dependent memory round trips.  Only the >16-byte tail of a long match keeps a (wave-uniform) loop.
 __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
     const uint32_t x0 = qa.a ^ qb.a, x1 = qa.b ^ qb.b, x2 = qa.c ^ qb.c, x3 = qa.d ^ qb.d;
     uint32_t len = x3 ? 12u + ((uint32_t)__ffs((int)x3) - 1u) / 8u : 16u;
@@ -396,6 +306,86 @@ __device__ __forceinline__ uint32_t lcp_tail(const uint8_t* a, const uint8_t* b,
     return n;
 }
 
+
+// Generic-depth form (levels 1-4: depth 4..16, lazy depths up to 4 and 2; src/libzling_lz.cpp:131-134).  Loops run
+// wave-uniformly (`while any lane is still walking`) with per-lane predicates instead of per-lane breaks: a divergent
+// break costs a handful of exec-mask instructions per lane group, a uniform loop costs one scalar branch.
+__device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, int ppos, uint32_t lctx, uint32_t first, uint32_t lov,
+                                            uint32_t m, int depth, uint32_t lhead, bool active, bool& veto, uint32_t& ld) {
+    Bucket B(dict, lctx);
+    uint32_t n = first;
+    active = active && n != 65535u;
+    const uint32_t probe = ld32u(buf + ppos + m);
+    for (int i = 0; i < depth && __any(active); i++) {
+        if (active) ld = min(ld, ring_dist(n, lhead));
+        const uint32_t off = lov & 0xFFFFFF;
+        const uint32_t srcw = ld32u(buf + (active ? off + m : (uint32_t)ppos));
+        const uint32_t nn = B.suffix[n & (kRing - 1)];
+        if (active && probe == srcw) { veto = true; active = false; }
+        active = active && nn != 65535u;
+        if (active) ld = min(ld, ring_dist(nn, lhead));
+        const uint32_t nov = B.offset[nn & (kRing - 1)];
+        active = active && !(off <= (nov & 0xFFFFFF));
+        n = nn; lov = nov;
+    }
+}
+
+__device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
+                                          const LevelCfg cfg, uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
+    const uint32_t head0 = heads[ctx];
+    const Quad qa = ld128u(buf + pos);               // bytes pos .. pos+15 (pos+275 < ilen)
+    const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
+    const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
+    Bucket B(dict, ctx), B1(dict, lctx1), B2(dict, lctx2);
+    const uint32_t lhead1 = heads[lctx1], lhead2 = heads[lctx2];
+    const uint32_t node0 = B.hash[hc];
+    const uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
+    const uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
+    uint32_t ov = B.offset[node0 & (kRing - 1)];
+    uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
+
+    uint32_t maxlen = kMatchMin - 1, maxnode = 0, node = node0, dmin = kRing - 1;
+    bool active = node0 != 65535u;
+    for (int i = 0; i < cfg.depth && __any(active); i++) {                 // src/libzling_lz.cpp:240-267
+        if (active) dmin = min(dmin, ring_dist(node, head0));
+        const uint32_t off = ov & 0xFFFFFF;
+        const bool cmp = active && (ov >> 24) == chk;
+        const Quad qb = ld128u(buf + (cmp ? off : (uint32_t)pos));
+        const uint32_t nov = B.offset[nx & (kRing - 1)];
+        const uint32_t nnx = B.suffix[nx & (kRing - 1)];
+        uint32_t len = cmp ? lcp16(qa, qb) : 0u;
+        const bool lng = cmp && len == 16u;
+        if (__any(lng)) { const uint32_t t = lcp_tail(buf + pos, buf + off, lng); len = lng ? t : len; }
+        if (len > maxlen) { maxlen = len; maxnode = node; }
+        active = active && maxlen != (uint32_t)kMatchMax && nx != 65535u;
+        if (active) dmin = min(dmin, ring_dist(nx, head0));
+        active = active && !(off <= (nov & 0xFFFFFF));
+        node = nx; ov = nov; nx = nnx;
+    }
+    uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
+    const bool lz = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
+    const uint32_t m = lz ? maxlen - 3u : 0u;
+    bool v1 = false, v2 = false;
+    uint32_t ld1 = kRing - 1, ld2 = kRing - 1;
+    if (want1) lazy_spec_u(dict, buf, pos + 1, lctx1, ln1, lov1, m, cfg.lazy1, lhead1, lz, v1, ld1);
+    if (want2) lazy_spec_u(dict, buf, pos + 2, lctx2, ln2, lov2, m, cfg.lazy2, lhead2, lz, v2, ld2);
+    if (v1) sp |= kSpVeto1;
+    if (v2) sp |= kSpVeto2;
+    if (ld1 < kRiskDist) sp |= kSpRisk1;
+    if (ld2 < kRiskDist) sp |= kSpRisk2;
+    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
+    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = key_ix(lctx2, hh2); S.lctx1 = lctx1; S.lctx2 = lctx2;
+    S.lz1 = lz && want1; S.lz2 = lz && want2;
+}
+
+// Level-0 form of speculate() (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130): the same
+// semantics written as straight-line predicated code.  Every divergent if / break in the generic form costs
+// a handful of exec-mask instructions, and one wavefront issues an instruction only every few cycles, so on
+// the level the benchmark runs the generic form spends most of phase 1 on control flow rather than on the
+// five dependent memory round trips.  Only the >16-byte tail of a long match keeps a (wave-uniform) loop.
 __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
                                              uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t head0 = heads[ctx];

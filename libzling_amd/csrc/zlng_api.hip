@@ -285,7 +285,8 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     int dummy;
     if (!err) err = &dummy;
     *err = ZLNG_OK;
-    if (level < 0 || level > 4 || max_blocks <= 0 || max_blocks > 8192) { *err = ZLNG_E_ARG; return nullptr; }
+    // 240 blocks (3.75 GiB) per call keeps every literal / token position inside 32 bits; larger streams are fed in several calls
+    if (level < 0 || level > 4 || max_blocks <= 0 || max_blocks > 240) { *err = ZLNG_E_ARG; return nullptr; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { *err = ZLNG_E_DEVICE; return nullptr; }
     hipDeviceProp_t prop;

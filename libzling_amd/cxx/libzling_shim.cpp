@@ -71,7 +71,7 @@ const size_t kBlock = ZLNG_BLOCK_SIZE;
 int batch_blocks() {
     const char* e = getenv("ZLNG_BATCH_BLOCKS");
     int n = e ? atoi(e) : 64;
-    return n < 1 ? 1 : (n > 4096 ? 4096 : n);
+    return n < 1 ? 1 : (n > 240 ? 240 : n);
 }
 int pick_device() {
     const char* e = getenv("ZLNG_DEVICE");
