@@ -79,10 +79,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # ZLNG_BENCH_ONE_DEVICE=1 (test hook): all ranks share cuda:0 and the few collectives go over gloo, so the
+    # N > 1 control flow can be exercised on a single-GPU box.  Numbers from that mode are not benchmarks.
+    one_dev = os.environ.get("ZLNG_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
+    cdev = "cpu" if one_dev else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     # ---- this rank's share of the workload
     from libzling_amd import sharding
@@ -101,17 +110,27 @@ def main():
     cap = zl.encode_bound(n)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     d_state = torch.empty(zl.MTF_STATE, dtype=torch.uint8, device="cuda")
+    h_state = torch.empty(zl.MTF_STATE, dtype=torch.uint8) if one_dev else None
     stream = zl.Stream(local, args.level, True, nb)
     init_state, init_level = stream.get_state()
 
     def step():
         if single:
+            if one_dev:                                            # gloo moves host tensors
+                def to_buf(b):
+                    lv = stream.get_state_device(d_state.data_ptr()); b.copy_(d_state.cpu()); return lv
+                def from_buf(b, lv):
+                    d_state.copy_(b); torch.cuda.synchronize(); stream.set_state_device(d_state.data_ptr(), lv)
+                buf = h_state
+            else:
+                to_buf = lambda b: stream.get_state_device(b.data_ptr())
+                from_buf = lambda b, lv: (torch.cuda.synchronize(), stream.set_state_device(b.data_ptr(), lv))
+                buf = d_state
             return sharding.run_handoff(
-                stream, rank, world, dist, d_state, init_state, init_level, args.level,
+                stream, rank, world, dist, buf, init_state, init_level, args.level,
                 parse=lambda: stream.parse_device(d_in.data_ptr(), n),
                 finish=lambda: stream.finish_device(d_out.data_ptr(), cap),
-                state_to_buf=lambda b: stream.get_state_device(b.data_ptr()),
-                buf_to_state=lambda b, lv: (torch.cuda.synchronize(), stream.set_state_device(b.data_ptr(), lv)))
+                state_to_buf=to_buf, buf_to_state=from_buf)
         stream.set_state(init_state, init_level)                   # a fresh stream every step
         return stream.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
 
@@ -132,10 +151,10 @@ def main():
     stage = dict(stream.timings())
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        sizes = torch.tensor([float(n), float(out_len)], dtype=torch.float64, device="cuda")
+        sizes = torch.tensor([float(n), float(out_len)], dtype=torch.float64, device=cdev)
         dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
         total_in, total_out = float(sizes[0].item()), float(sizes[1].item())
     else:
