@@ -46,3 +46,27 @@ def test_cli_rejects_corrupt_stream(tmp_path):
     bad.write_bytes(bytes([9, 1, 2, 3]))
     r = subprocess.run([DEMO, "d", str(bad), str(tmp_path / "x")], stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"invalid encflag" in r.stderr
+
+
+def test_stream_state_is_carried_across_calls(oracle):
+    """The shim feeds a long stream to the GPU in several calls (ZLNG_BATCH_BLOCKS); MTF tables and level state must
+    persist in the context between them (src/libzling.cpp:185,197: the reference reuses one encoder object)."""
+    x = corpus.get("carry_2blk")
+    want = oracle.encode(x, 0)
+    env = dict(os.environ, ZLNG_BATCH_BLOCKS="1")
+    p = subprocess.run([DEMO, "e0"], input=x.tobytes(), stdout=subprocess.PIPE, check=True, env=env)
+    assert np.array_equal(np.frombuffer(p.stdout, dtype=np.uint8), want)
+    q = subprocess.run([DEMO, "d"], input=p.stdout, stdout=subprocess.PIPE, check=True, env=env)
+    assert q.stdout == x.tobytes()
+
+
+def test_python_stream_called_block_by_block(oracle):
+    import libzling_amd as zl
+    from oracle_py import textgen
+    x = textgen(2 * zl.BLOCK + 500_000, 91)
+    want = oracle.encode(x, 4)
+    parts = []
+    with zl.Stream(0, 4, True, 1) as s:
+        for off in range(0, x.size, zl.BLOCK):
+            parts.append(s.encode(x[off:off + zl.BLOCK]))
+    assert np.array_equal(np.concatenate(parts), want)
