@@ -251,13 +251,19 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
                     const uint32_t src = ufl(r[(head - (v >> 16)) & (kRing - 1)]);
                     if (opos + mlen > sb.encpos || src >= opos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
                     const uint32_t dist = opos - src;
-                    if (dist >= 64 || dist >= mlen) {
-                        for (uint32_t j = lane; j < mlen; j += 64) out[opos + j] = out[src + j];
-                    } else {                                          // overlapping: period `dist` (forward byte copy, :91-104)
-                        for (uint32_t j = lane; j < mlen; j += 64) out[opos + j] = out[src + j % dist];
+                    // cooperative forward copy (src/libzling_lz.cpp:91-104 semantics: byte j comes from src + j, which for
+                    // an overlapping match is the period-`dist` pattern); every lane keeps the last byte it moved so the
+                    // new context bytes come from registers instead of re-reading bytes that were just stored
+                    uint32_t lastv = 0;
+                    for (uint32_t j = lane; j < mlen; j += 64) {
+                        const uint32_t sj = (dist >= 64 || dist >= mlen) ? j : j % dist;
+                        lastv = out[src + sj];
+                        out[opos + j] = (uint8_t)lastv;
                     }
                     opos += mlen;
-                    b3 = ufl(out[opos - 3]); b2 = ufl(out[opos - 2]); b1 = ufl(out[opos - 1]);
+                    b1 = (uint32_t)__builtin_amdgcn_readlane((int)lastv, (int)((mlen - 1) & 63));
+                    b2 = (uint32_t)__builtin_amdgcn_readlane((int)lastv, (int)((mlen - 2) & 63));
+                    b3 = (uint32_t)__builtin_amdgcn_readlane((int)lastv, (int)((mlen - 3) & 63));
                     const uint32_t w = b2 << 8 | b1;
                     const uint32_t m = ufl(mru[b3]);
                     if (lane == 0 && (m & 0xFFFF) != w) mru[b3] = (m << 16) | w;
