@@ -283,6 +283,10 @@ struct Spec {
     uint32_t sp, node0, head0, dmin;
     uint32_t lkix1, lkix2, lctx1, lctx2;
     bool lz1, lz2;
+    // level 0 only, for resolving same-slot conflicts in registers: candidate length of the first chain node
+    // alone, the lazy probe's source offset (bit 31: probe chain non-empty), the 16 input bytes at the position
+    uint32_t len0, lsrc1;
+    Quad qa;
 };
 
 __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
@@ -433,10 +437,11 @@ __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8
     const uint32_t probe = ld32u(buf + pos + 1 + m);
     const uint32_t srcw = ld32u(buf + ((lz1 && hasl) ? (lov1 & 0xFFFFFF) + m : (uint32_t)pos));
     if (lz1 && hasl && probe == srcw) sp |= kSpVeto1;
-    if (lz1 && hasl && ring_dist(ln1, lhead1) < kRiskDist) sp |= kSpRisk1;
+    if (hasl && ring_dist(ln1, lhead1) < kRiskDist) sp |= kSpRisk1;      // (kept even when no probe was needed: the conflict fix may need one)
     S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
     S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = 0; S.lctx1 = lctx1; S.lctx2 = 0;
     S.lz1 = lz1; S.lz2 = false;
+    S.len0 = len0; S.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u); S.qa = qa;
 }
 
 // Ordering point for LDS traffic inside ONE wavefront (program order is execution order for a wave's LDS
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     __shared__ unsigned long long ctxtab[256];
     __shared__ unsigned long long evtab[kEvTab];
     __shared__ unsigned long long ektab[256];
+    __shared__ unsigned long long pred_mask;         // lanes that are the in-slot predecessor of a later lane of the same commit set
     __shared__ int pf_pos, pf_level, pf_done;        // round start / level / end flag published for the prefetch wave
     const uint32_t blk = blockIdx.x;
     const size_t base = (size_t)blk * kBlockIn;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     uint32_t nt = 0;
     int q = 0, nsub = 0;
     unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
-    unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0;
+    unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0;
     const bool prof = a.dbg != nullptr;
 
     while (q < ilen) {                               // ---- one sub-block (one EncodeImpl call)
@@ -549,6 +555,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             Spec S;
             S.sp = kMatchMin - 1; S.node0 = 65535; S.head0 = 0; S.dmin = kRing - 1;
             S.lkix1 = S.lkix2 = S.lctx1 = S.lctx2 = 0; S.lz1 = S.lz2 = false;
+            S.len0 = 0; S.lsrc1 = 0; S.qa = Quad{0, 0, 0, 0};
             if (canm) {
                 atomicOr(&keytab[kix], lane_bit);
                 atomicOr(&ctxtab[ctx], lane_bit);
@@ -564,7 +571,9 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             if (canm) { keymask = keytab[kix]; ctxmask = ctxtab[ctx]; }
             // a lazy probe is invalidated by an accepted insert with its key, or -- if it walked near the
             // ring head -- by any accepted insert into its bucket
-            if (lz1) lkey |= keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
+            // (at level 0 the probe's read set is kept for every lane: the in-register conflict fix can change a length
+            //  and then needs a probe the speculation did not evaluate)
+            if (lz1 || (level0 && canm)) lkey |= keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
             if (lz2) lkey |= keytab[lkix2] | ((sp & kSpRisk2) ? ctxtab[lctx2] : 0ull);
             const unsigned long long hitmask = live ? evtab[chix] : 0ull;   // boundaries whose (key, word) may equal my check
             const unsigned long long samekey = live ? ektab[ek] : 0ull;     // boundaries with my event key
@@ -605,6 +614,8 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             const bool near_cut = opos + 2 * 64 + 4 >= kSubSyms;
 
             // exact scalar replay of the token at q (wave-uniform): boundary event, match_exact / word MRU / literal
+            // per-lane insert link and match node actually used (the in-register conflict fix may override the speculation)
+            uint32_t node0w = node0, mnode = (sp >> kSpNodeShift) & (kRing - 1);
             auto serial_token = [&](bool use_spec) {
                 const int sl = q - P;
                 const uint32_t xk = rl(ek, sl), xw = rl(ew, sl);
@@ -620,13 +631,13 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
                     if (use_spec) {                  // speculation validated by the caller: insert + speculative result
                         if (lane == sl) {
                             Bucket B(dict, ctx);
-                            B.suffix[head] = (uint16_t)node0;
+                            B.suffix[head] = (uint16_t)node0w;
                             B.offset[head] = (uint32_t)pos | chk << 24;
                             B.hash[hc] = (uint16_t)head;
                         }
                         is_match = ((match_lanes >> sl) & 1ull) != 0;
                         mlen = (int)(spq & kSpLenMask);
-                        midx = (int)((head - ((spq >> kSpNodeShift) & (kRing - 1))) & (kRing - 1));
+                        midx = (int)((head - rl(mnode, sl)) & (kRing - 1));
                     } else {
                         int mi = 0, ml = 0;
                         const bool hit = match_exact(dict, buf, q, cfg, head, lane == 0, mi, ml);
@@ -669,16 +680,82 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
                     else { seg = 0; while (s < 64) { seg |= rl64(hop_mask, s); s = (int)rl(hop_next, s); } }
                     if (prof) c_chase += __builtin_readcyclecounter() - tc;
                     // ---- validate every lane against (acc | seg); only lanes of seg matter
+                    unsigned long long tv = 0;
+                    if (prof) tv = __builtin_readcyclecounter();
                     const unsigned long long all = acc | seg;
                     const uint32_t k = (uint32_t)__popcll(ctxmask & all & below);
-                    const bool dirty = canm && (((keymask & all & below) != 0) || dmin <= k);
-                    const bool ldirty = spec_len >= (uint32_t)kMatchMin && (lkey & all & beloweq) != 0;
+                    const unsigned long long kq = canm ? (keymask & all & below) : 0ull;   // accepted earlier starts in my hash slot
+                    const bool ring = canm && dmin <= k;
+                    // ---- same-slot conflicts resolved in registers (level 0).  An earlier accepted start p with my
+                    // (ctx, hash13) is now the head of my chain and its predecessor in the slot -- an even earlier such
+                    // start p2, else the node my speculation started from -- is the second and last node examined
+                    // (depth 2): the true result is best-of {p, p2 | node0} under the reference's rules
+                    // (src/libzling_lz.cpp:240-267).  It is taken only if it leaves the token's length unchanged, so
+                    // the chase stays valid; everything else falls back to the restart / exact-replay path.
+                    bool fixed_ok = false;
+                    int pfix = 0;
+                    node0w = node0; mnode = (sp >> kSpNodeShift) & (kRing - 1);
+                    const bool inseg = (seg & lane_bit) != 0;
+                    if (level0 && __any(inseg && kq != 0 && !ring)) {
+                        const bool cand = inseg && kq != 0 && !ring;
+                        const int p = kq ? top_bit(kq) : 0;
+                        const unsigned long long kq2 = kq & ~(1ull << p);
+                        const bool has2 = kq2 != 0;
+                        const int p2 = has2 ? top_bit(kq2) : 0;
+                        const uint32_t key = ctx << 13 | hc;
+                        const uint32_t key_p = (uint32_t)__shfl((int)key, p), chk_p = (uint32_t)__shfl((int)chk, p);
+                        const Quad qp = {(uint32_t)__shfl((int)S.qa.a, p), (uint32_t)__shfl((int)S.qa.b, p),
+                                         (uint32_t)__shfl((int)S.qa.c, p), (uint32_t)__shfl((int)S.qa.d, p)};
+                        uint32_t key_p2 = key, chk_p2 = 0;
+                        Quad qp2 = {0, 0, 0, 0};
+                        if (__any(cand && has2)) {
+                            key_p2 = (uint32_t)__shfl((int)key, p2); chk_p2 = (uint32_t)__shfl((int)chk, p2);
+                            qp2 = Quad{(uint32_t)__shfl((int)S.qa.a, p2), (uint32_t)__shfl((int)S.qa.b, p2),
+                                       (uint32_t)__shfl((int)S.qa.c, p2), (uint32_t)__shfl((int)S.qa.d, p2)};
+                        }
+                        const bool fixable = cand && key_p == key && (!has2 || key_p2 == key);
+                        // candidate of p
+                        const bool cp = fixable && chk_p == chk;
+                        uint32_t rp = cp ? lcp16(S.qa, qp) : 0u;
+                        const bool lp = cp && rp == 16u;
+                        if (__any(lp)) { const uint32_t t = lcp_tail(buf + pos, buf + P + p, lp); rp = lp ? t : rp; }
+                        // candidate of the second node
+                        const bool c2 = fixable && has2 && chk_p2 == chk;
+                        uint32_t r2 = c2 ? lcp16(S.qa, qp2) : 0u;
+                        const bool l2 = c2 && r2 == 16u;
+                        if (__any(l2)) { const uint32_t t = lcp_tail(buf + pos, buf + P + p2, l2); r2 = l2 ? t : r2; }
+                        const uint32_t slot_p = (head0 + (uint32_t)__popcll(ctxmask & all & ((1ull << p) - 1ull)) + 1u) & (kRing - 1);
+                        const uint32_t slot_p2 = (head0 + (uint32_t)__popcll(ctxmask & all & ((1ull << p2) - 1ull)) + 1u) & (kRing - 1);
+                        const bool second = has2 || node0 != 65535u;
+                        const uint32_t rs = has2 ? r2 : S.len0, ns = has2 ? slot_p2 : node0;
+                        uint32_t ml = kMatchMin - 1, mn = 0;
+                        if (rp > ml) { ml = rp; mn = slot_p; }
+                        if (ml != (uint32_t)kMatchMax && second && rs > ml) { ml = rs; mn = ns; }
+                        // lazy probe under the (possibly different) length; its own read set must be clean
+                        const bool lzn = ml >= (uint32_t)kMatchMin && ml < (uint32_t)kLazyLimit;
+                        const bool lclean = (lkey & all & beloweq) == 0 || !lzn;
+                        bool veto = (sp & kSpVeto1) != 0;
+                        const bool reprobe = fixable && lzn && lclean && ml != spec_len;
+                        if (__any(reprobe)) {
+                            const uint32_t mm = reprobe ? ml - 3u : 0u;
+                            const uint32_t pr = ld32u(buf + pos + 1 + mm);
+                            const uint32_t sr = ld32u(buf + (reprobe ? (S.lsrc1 & 0xFFFFFF) + mm : (uint32_t)pos));
+                            if (reprobe) veto = (S.lsrc1 >> 31) != 0 && pr == sr;
+                        }
+                        const bool nmatch = ml >= (uint32_t)kMatchMin && !(lzn && veto);
+                        fixed_ok = fixable && lclean && nmatch == spec_match && (!nmatch || ml == spec_len);
+                        if (fixed_ok) { node0w = slot_p; mnode = mn; pfix = p; }
+                    }
+                    const bool dirty = canm && (kq != 0 || ring) && !fixed_ok;
+                    const bool ldirty = !fixed_ok && spec_len >= (uint32_t)kMatchMin && spec_len < (uint32_t)kLazyLimit && (lkey & all & beloweq) != 0;
                     const uint32_t m0 = mru[ctx];
                     const bool poss = !spec_match && pos + 1 < ilen &&
                                       ((m0 & 0xFFFF) == cw || (m0 >> 16) == cw || (hitmask & all & beloweq) != 0);
                     const unsigned long long prob = seg & __ballot(dirty || ldirty || poss);
                     const int f = prob ? (int)__builtin_ctzll(prob) : 64;
                     const unsigned long long com = f >= 64 ? seg : (seg & ((1ull << f) - 1ull));
+                    unsigned long long tcm = 0;
+                    if (prof) { tcm = __builtin_readcyclecounter(); c_val += tcm - tv; }
                     if (com) {
                         const bool mine = (com & lane_bit) != 0;
                         // ---- MRU events of the committed boundaries (lane-parallel 2-slot push rules)
@@ -703,15 +780,25 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
                         (void)first;
                         // ---- dictionary inserts (src/libzling_lz.cpp:227-230) and token words
                         const uint32_t head = (head0 + k + 1u) & (kRing - 1);
+                        bool head_writer = true;
+                        if (__any(mine && fixed_ok)) {               // a fixed lane's predecessor p has the same exact key
+                            if (lane == 0) pred_mask = 0;
+                            wsync();
+                            if (mine && fixed_ok) atomicOr(&pred_mask, 1ull << pfix);
+                            wsync();
+                            head_writer = ((pred_mask >> lane) & 1ull) == 0;
+                        }
                         if (mine) {
                             uint32_t word;
                             if (canm) {
                                 Bucket B(dict, ctx);
-                                B.suffix[head] = (uint16_t)node0;
+                                B.suffix[head] = (uint16_t)node0w;
                                 B.offset[head] = (uint32_t)pos | chk << 24;
-                                B.hash[hc] = (uint16_t)head;
+                                // several starts of one hash slot can commit together now; the slot's head must end up
+                                // being the last of them, so a lane that is the predecessor of a later one does not write it
+                                if (head_writer) B.hash[hc] = (uint16_t)head;
                             }
-                            if (spec_match) word = (258u + spec_len - kMatchMin) | ((head - ((sp >> kSpNodeShift) & (kRing - 1))) & (kRing - 1)) << 16;
+                            if (spec_match) word = (258u + spec_len - kMatchMin) | ((head - mnode) & (kRing - 1)) << 16;
                             else word = b_0 | ctx << 16;
                             tok[nt + (uint32_t)__popcll(com & below)] = word;
                         }
@@ -723,6 +810,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
                         q = P + lastl + (int)rl(tlen, lastl);
                         prevty = last_match ? kTyMatch : kTyLit;
                     }
+                    if (prof) c_com += __builtin_readcyclecounter() - tcm;
                     if (f < 64) {
                         const bool conflict = rl((dirty || ldirty) ? 1u : 0u, f) != 0;
                         if (prof && conflict) {
@@ -761,7 +849,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     if (lane == 0) { __atomic_store_n(&pf_done, 1, __ATOMIC_RELAXED); a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt; }
     if (prof && lane == 0) {
         unsigned long long* d = a.dbg + (size_t)blk * 16;
-        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same;
+        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same; d[15] = c_val; d[11] = c_com;
     }
 }
 

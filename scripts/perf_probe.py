@@ -36,6 +36,7 @@ if os.environ.get("ZLNG_PROFILE") == "1":
     for b in range(min(nb, 4)):
         d = buf[16 * b: 16 * b + 8]
         e = buf[16 * b + 8: 16 * b + 16]
+        print("   validate %.0f cyc/round, commit %.0f cyc/round" % (e[7] / max(d[3], 1), e[3] / max(d[3], 1)))
         print("   conflicts: same-key %d ring %d lazy-only %d | exact replays %d of which result == speculation %d" % (e[2], e[3], e[4], e[5], e[6]))
         print("   serial-token cycles %.0fM (%.0f per problem token), chase %.0fM (%.0f per round)" % (e[0] / 1e6, e[0] / max(d[6] + d[7], 1), e[1] / 1e6, e[1] / max(d[3], 1)))
         tot = d[0] + d[1] + d[2]
