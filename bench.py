@@ -190,7 +190,7 @@ def main():
                        "shard": ("one stream sharded by block range, MTF state hand-off over RCCL" if single
                                  else "one independent stream per GPU"),
                        "input_bytes_total": int(total_in), "zlng_bytes_total": int(total_out)},
-            "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 3),
+            "roofline": {"bound": "hbm", "kernel": "%s (stage %s)" % (kmap.get(dom, dom), dom), "kernel_ms": round(dom_ms, 3),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes": int(alg_bytes)},
