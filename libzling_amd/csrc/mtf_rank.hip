@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
         "s_ff1_i32_b64 %[i], %[m0]\n\t"                                                            \
         : [t0] "+v"(t0), [m0] "=&s"(M0), [m1] "=&s"(m1_), [i] "=&s"(i), [cv] "=&v"(cv)             \
         : [c] "s"(c)                                                                               \
-        : "vcc")
+        : "vcc", "scc")
 
 #define ZLNG_MTF_STEP(K)                                                                           \
     {                                                                                              \
@@ -201,13 +201,93 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
         RANKSTORE(i, K);                                                                           \
     }
 
+// Full tiles use a tighter form of the same step, shaped by scripts/ubench/mtfstep.hip (one lone wavefront on
+// gfx950: the shipped order above costs 32 ns/step, this one 25 ns): the table chain never leaves the vector
+// unit -- up[l] = t0[l+1] (DPP wave_shl:1), "c sits one lane up" = v_cmp_eq(c, up) replaces s_not + s_lshr, and
+// the value that lane takes is up itself, so c is only ever a scalar operand (no v_mov) -- the slow-path branch
+// hangs off ONE s_andn2 of vcc with the lane 0..20 mask (SCC = "hit in the fast lanes"), vector and scalar
+// instructions stay grouped (interleaving them measured slower), and eight literals are fetched by eight
+// back-to-back v_readlane in front of their steps.  up's lane 63 is never written (no lane 64 to read): it keeps
+// 0xFFFFFFFF, which no literal equals.
+// DPP hazard (gfx9: VALU write -> DPP read of the same VGPR needs 2 wait states): t0's last VALU writer is the
+// previous step's second select, followed by s_andn2 / s_cbranch / s_ff1 / v_writelane; the slow path ends in s_nop 1.
+// One statement covers eight literals (an asm goto with outputs crashes this compiler's instruction selection,
+// and a C-level branch per step costs one more scalar instruction): a step whose hit is not in lanes 0..20
+// jumps to the end of the statement with its (empty) fast-lane mask in m0; the C code after the statement finds
+// the step from the first rank lane still holding the tile's 0xFFFFFFFF fill, replays that literal on the slow
+// path and the rest of the group with ZLNG_MTF_STEP.
+#define ZLNG_MTF_G_STEP(C, K)                                                                                   \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t"                                                                \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t"                                                              \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                      \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t"                                                          \
+    "s_andn2_b64 %[hm], 0x1fffff, vcc\n\t"                                                                      \
+    "s_cbranch_scc0 1" #K "f\n\t"                                                                               \
+    "s_ff1_i32_b64 %[i], %[hm]\n\t"                                                                             \
+    "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
+    "2" #K ":\n\t"
+// Out-of-line part of step K (all 64 sit behind the 64 steps): the hit was not in lanes 0..20.
+//   rank 21..63: the step has already swapped c with its left neighbour; from that state the reference's
+//     swap(table[rank], table[mtfnext[rank]]) is  t0[rank-1] = t0[rank];  t0[rank] = t0[next];  t0[next] = c
+//     (next <= rank - 2 from rank 21 on, so t0[next] is untouched).  mtfnext = (rank * 62263) >> 16 below 128.
+//   rank >= 64 (c not in t0, nothing was changed): leave the statement with hm = 0.
+// v_readlane / v_writelane lane selects come from SALU results or M0 (no wait states owed); the closing s_nop
+// covers the v_writelane -> DPP read of t0 in the next step.
+#define ZLNG_MTF_G_SLOW(C, K)                                                                                   \
+    "1" #K ":\n\t"                                                                                              \
+    "s_not_b64 %[hm], vcc\n\t"                                                                                  \
+    "s_cbranch_scc0 9f\n\t"                                                                                     \
+    "s_ff1_i32_b64 %[i], %[hm]\n\t"                                                                             \
+    "s_mul_i32 %[nx], %[i], 0xf337\n\t"                                                                         \
+    "s_lshr_b32 %[nx], %[nx], 16\n\t"                                                                           \
+    "v_readlane_b32 %[d], %[t0], %[i]\n\t"                                                                      \
+    "s_sub_u32 m0, %[i], 1\n\t"                                                                                 \
+    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
+    "v_readlane_b32 %[d], %[t0], %[nx]\n\t"                                                                     \
+    "s_mov_b32 m0, %[i]\n\t"                                                                                    \
+    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "v_writelane_b32 %[t0], %[" #C "], m0\n\t"                                                                  \
+    "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
+    "s_nop 1\n\t"                                                                                               \
+    "s_branch 2" #K "b\n\t"
+#define ZLNG_MTF_G8(M, A, B, C, D, E, F, G, H) M(c0, A) M(c1, B) M(c2, C) M(c3, D) M(c4, E) M(c5, F) M(c6, G) M(c7, H)
+#define ZLNG_MTF_G_FETCH(A, B, C, D, E, F, G, H)                                                                \
+    "v_readlane_b32 %[c0], %[v], " #A "\n\tv_readlane_b32 %[c1], %[v], " #B "\n\t"                              \
+    "v_readlane_b32 %[c2], %[v], " #C "\n\tv_readlane_b32 %[c3], %[v], " #D "\n\t"                              \
+    "v_readlane_b32 %[c4], %[v], " #E "\n\tv_readlane_b32 %[c5], %[v], " #F "\n\t"                              \
+    "v_readlane_b32 %[c6], %[v], " #G "\n\tv_readlane_b32 %[c7], %[v], " #H "\n\t"
+#define ZLNG_MTF_G_FAST(A, B, C, D, E, F, G, H) ZLNG_MTF_G_FETCH(A, B, C, D, E, F, G, H) ZLNG_MTF_G8(ZLNG_MTF_G_STEP, A, B, C, D, E, F, G, H)
+// (A slow part runs before its group's successor fetches c0..c7 again, so its literal is still in its register.)
+
+// A whole 64-literal tile in ONE statement.  hm == 0 afterwards: a literal of rank >= 64 stopped it; the first
+// rank lane still holding the tile's 0xFFFFFFFF fill is that literal.
+#define ZLNG_MTF_TILE()                                                                                         \
+    asm volatile(                                                                                               \
+        ZLNG_MTF_G_FAST(0, 1, 2, 3, 4, 5, 6, 7)         ZLNG_MTF_G_FAST(8, 9, 10, 11, 12, 13, 14, 15)           \
+        ZLNG_MTF_G_FAST(16, 17, 18, 19, 20, 21, 22, 23) ZLNG_MTF_G_FAST(24, 25, 26, 27, 28, 29, 30, 31)         \
+        ZLNG_MTF_G_FAST(32, 33, 34, 35, 36, 37, 38, 39) ZLNG_MTF_G_FAST(40, 41, 42, 43, 44, 45, 46, 47)         \
+        ZLNG_MTF_G_FAST(48, 49, 50, 51, 52, 53, 54, 55) ZLNG_MTF_G_FAST(56, 57, 58, 59, 60, 61, 62, 63)         \
+        "s_branch 9f\n\t"                                                                                       \
+        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 0, 1, 2, 3, 4, 5, 6, 7)         ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 8, 9, 10, 11, 12, 13, 14, 15)   \
+        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 16, 17, 18, 19, 20, 21, 22, 23) ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 24, 25, 26, 27, 28, 29, 30, 31) \
+        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 32, 33, 34, 35, 36, 37, 38, 39) ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 40, 41, 42, 43, 44, 45, 46, 47) \
+        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 48, 49, 50, 51, 52, 53, 54, 55) ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 56, 57, 58, 59, 60, 61, 62, 63) \
+        "9:"                                                                                                    \
+        : [t0] "+v"(t0), [up] "+v"(up), [ranks] "+v"(ranks), [hm] "=&s"(hm_), [m1] "=&s"(m1_), [i] "=&s"(i_),   \
+          [nx] "=&s"(nx_), [d] "=&s"(d_), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3),       \
+          [c4] "=&s"(c4), [c5] "=&s"(c5), [c6] "=&s"(c6), [c7] "=&s"(c7)                                        \
+        : [v] "v"(v)                                                                                            \
+        : "vcc", "scc")
+
 __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     const uint32_t ctx = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     uint8_t* st = a.state + ctx * 256;
     uint32_t t0 = st[lane], t1 = st[64 + lane], t2 = st[128 + lane], t3 = st[192 + lane];
 
-    auto slow_step = [&](uint32_t c) -> uint32_t {                     // rank >= 64
+    auto slow_step = [&](uint32_t c) __attribute__((always_inline)) -> uint32_t {                     // rank >= 64
         const uint64_t m1 = __ballot(t1 == c), m2 = __ballot(t2 == c), m3 = __ballot(t3 == c);
         const uint32_t i = m1 ? 64 + (uint32_t)__builtin_ctzll(m1)
                               : (m2 ? 128 + (uint32_t)__builtin_ctzll(m2) : 192 + (uint32_t)__builtin_ctzll(m3));
@@ -221,6 +301,7 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
         return i;
     };
 
+    uint32_t up = 0xFFFFFFFFu;                                         // ZLNG_MTF_TILE: t0 shifted down one lane
     uint8_t* run = a.lit_byte + a.ctx_off[ctx];
     const uint32_t n = a.ctx_total[ctx];
     uint32_t vnext = lane < n ? (uint32_t)run[lane] : 0u;
@@ -228,26 +309,29 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
         const uint32_t v = vnext;
         const uint32_t nidx = base + 64 + lane;
         vnext = nidx < n ? (uint32_t)run[nidx] : 0u;                   // next tile in flight while this one is replayed
-        uint32_t ranks = 0;
+        uint32_t ranks = 0xFFFFFFFFu;
         if (base + 64 <= n) {
-#define RANKSTORE(I, K) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(ranks) : "s"(I), "i"(K))
-            ZLNG_MTF_STEP(0)  ZLNG_MTF_STEP(1)  ZLNG_MTF_STEP(2)  ZLNG_MTF_STEP(3)  ZLNG_MTF_STEP(4)  ZLNG_MTF_STEP(5)  ZLNG_MTF_STEP(6)  ZLNG_MTF_STEP(7)
-            ZLNG_MTF_STEP(8)  ZLNG_MTF_STEP(9)  ZLNG_MTF_STEP(10) ZLNG_MTF_STEP(11) ZLNG_MTF_STEP(12) ZLNG_MTF_STEP(13) ZLNG_MTF_STEP(14) ZLNG_MTF_STEP(15)
-            ZLNG_MTF_STEP(16) ZLNG_MTF_STEP(17) ZLNG_MTF_STEP(18) ZLNG_MTF_STEP(19) ZLNG_MTF_STEP(20) ZLNG_MTF_STEP(21) ZLNG_MTF_STEP(22) ZLNG_MTF_STEP(23)
-            ZLNG_MTF_STEP(24) ZLNG_MTF_STEP(25) ZLNG_MTF_STEP(26) ZLNG_MTF_STEP(27) ZLNG_MTF_STEP(28) ZLNG_MTF_STEP(29) ZLNG_MTF_STEP(30) ZLNG_MTF_STEP(31)
-            ZLNG_MTF_STEP(32) ZLNG_MTF_STEP(33) ZLNG_MTF_STEP(34) ZLNG_MTF_STEP(35) ZLNG_MTF_STEP(36) ZLNG_MTF_STEP(37) ZLNG_MTF_STEP(38) ZLNG_MTF_STEP(39)
-            ZLNG_MTF_STEP(40) ZLNG_MTF_STEP(41) ZLNG_MTF_STEP(42) ZLNG_MTF_STEP(43) ZLNG_MTF_STEP(44) ZLNG_MTF_STEP(45) ZLNG_MTF_STEP(46) ZLNG_MTF_STEP(47)
-            ZLNG_MTF_STEP(48) ZLNG_MTF_STEP(49) ZLNG_MTF_STEP(50) ZLNG_MTF_STEP(51) ZLNG_MTF_STEP(52) ZLNG_MTF_STEP(53) ZLNG_MTF_STEP(54) ZLNG_MTF_STEP(55)
-            ZLNG_MTF_STEP(56) ZLNG_MTF_STEP(57) ZLNG_MTF_STEP(58) ZLNG_MTF_STEP(59) ZLNG_MTF_STEP(60) ZLNG_MTF_STEP(61) ZLNG_MTF_STEP(62) ZLNG_MTF_STEP(63)
+            uint32_t c0, c1, c2, c3, c4, c5, c6, c7, i_, nx_, d_;
+            uint64_t hm_, m1_;
+            ZLNG_MTF_TILE();
+            if (__builtin_expect(hm_ == 0, 0)) {
+#define RANKSTORE(I, K) wrl(ranks, I, K)
+                const uint32_t kk = (uint32_t)__builtin_ctzll(__ballot(ranks == 0xFFFFFFFFu));
+                const uint32_t r = slow_step(rdl(v, kk));
+                wrl(ranks, r, kk);
+                for (uint32_t k = kk + 1; k < 64u; k++) ZLNG_MTF_STEP(k)
 #undef RANKSTORE
-            run[base + lane] = (uint8_t)ranks;
+            }
         } else {
 #define RANKSTORE(I, K) wrl(ranks, I, K)
             const uint32_t cnt = n - base;
             for (uint32_t k = 0; k < cnt; k++) ZLNG_MTF_STEP(k)
 #undef RANKSTORE
-            if (lane < cnt) run[base + lane] = (uint8_t)ranks;
         }
+        // take delivery of the next tile BEFORE issuing the rank store: vmcnt retires in order, so a wait for
+        // the (long finished) load placed after the store would also wait for the store's round trip
+        asm volatile("" : "+v"(vnext));
+        if (base + lane < n) run[base + lane] = (uint8_t)ranks;
     }
     st[lane] = (uint8_t)t0; st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
 }

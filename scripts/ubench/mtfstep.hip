@@ -1,0 +1,230 @@
+// Variants of the k_mtf_dense fast step, timed on one lone wavefront (test tool, not product).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define ITER 200000
+#define COMMON_OUT [t0] "+v"(t0), [ranks] "+v"(ranks), [m0] "=&s"(m0), [m1] "=&s"(m1), [i] "=&s"(idx), [c] "=&s"(c), [cv] "=&v"(cv), [up] "+v"(up)
+#define DECL unsigned t0 = threadIdx.x, v = (threadIdx.x * 7 + 3) & 15, ranks = 0, idx, c, cv, up = 0xffffffffu; unsigned long long m0, m1;
+#define FIN out[threadIdx.x] = t0 * 31 + ranks;
+
+// P0: the shipped order
+#define P0(K) asm volatile("v_readlane_b32 %[c], %[v], " #K "\n\tv_mov_b32 %[cv], %[c]\n\tv_cmp_ne_u32_e32 vcc, %[cv], %[t0]\n\t" \
+    "s_not_b64 %[m0], vcc\n\ts_lshr_b64 %[m1], %[m0], 1\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[cv], %[m1]\n\ts_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "s_cmp_lt_u32 %[i], 21\n\ts_cbranch_scc0 1f\n\t1: v_writelane_b32 %[ranks], %[i], " #K "\n\t" \
+    : COMMON_OUT : [v] "v"(v) : "vcc", "scc")
+__global__ void k_p0(unsigned* out) { DECL for (int it = 0; it < ITER; it++) { P0(0); P0(1); P0(2); P0(3); } FIN }
+
+// P0 without the compare+branch
+#define P0NB(K) asm volatile("v_readlane_b32 %[c], %[v], " #K "\n\tv_mov_b32 %[cv], %[c]\n\tv_cmp_ne_u32_e32 vcc, %[cv], %[t0]\n\t" \
+    "s_not_b64 %[m0], vcc\n\ts_lshr_b64 %[m1], %[m0], 1\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[cv], %[m1]\n\ts_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "v_writelane_b32 %[ranks], %[i], " #K "\n\t" \
+    : COMMON_OUT : [v] "v"(v) : "vcc", "scc")
+__global__ void k_p0nb(unsigned* out) { DECL for (int it = 0; it < ITER; it++) { P0NB(0); P0NB(1); P0NB(2); P0NB(3); } FIN }
+
+// P0 without the rank store
+#define P0NS(K) asm volatile("v_readlane_b32 %[c], %[v], " #K "\n\tv_mov_b32 %[cv], %[c]\n\tv_cmp_ne_u32_e32 vcc, %[cv], %[t0]\n\t" \
+    "s_not_b64 %[m0], vcc\n\ts_lshr_b64 %[m1], %[m0], 1\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[cv], %[m1]\n\ts_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "s_cmp_lt_u32 %[i], 21\n\ts_cbranch_scc0 1f\n\t1:\n\t" \
+    : COMMON_OUT : [v] "v"(v) : "vcc", "scc")
+__global__ void k_p0ns(unsigned* out) { DECL for (int it = 0; it < ITER; it++) { P0NS(0); P0NS(1); P0NS(2); P0NS(3); } FIN }
+
+// P2: all-VALU table chain: up = t0[l+1]; m1 = (up == c); rank from ~vcc off the chain
+#define P2(K) asm volatile("v_readlane_b32 %[c], %[v], " #K "\n\t" \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[c], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[c], %[up]\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_not_b64 %[m0], vcc\n\ts_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "s_cmp_lt_u32 %[i], 21\n\ts_cbranch_scc0 1f\n\t1: v_writelane_b32 %[ranks], %[i], " #K "\n\t" \
+    : COMMON_OUT : [v] "v"(v) : "vcc", "scc")
+__global__ void k_p2(unsigned* out) { DECL for (int it = 0; it < ITER; it++) { P2(0); P2(1); P2(2); P2(3); } FIN }
+
+// P3: P2 with the branch taken from one s_andn2 on vcc (SCC = any hit in lanes 0..20), rank from that mask
+#define P3(K) asm volatile("v_readlane_b32 %[c], %[v], " #K "\n\t" \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[c], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[c], %[up]\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 %[m0], 0x1fffff, vcc\n\ts_cbranch_scc0 1f\n\t1: s_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "v_writelane_b32 %[ranks], %[i], " #K "\n\t" \
+    : COMMON_OUT : [v] "v"(v) : "vcc", "scc")
+__global__ void k_p3(unsigned* out) { DECL for (int it = 0; it < ITER; it++) { P3(0); P3(1); P3(2); P3(3); } FIN }
+
+// P4: P3 with the four literal fetches hoisted in front of the four steps (c0..c3)
+#define P4BODY(C, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 %[m0], 0x1fffff, vcc\n\ts_cbranch_scc0 1f\n\t1: s_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "v_writelane_b32 %[ranks], %[i], " #K "\n\t"
+__global__ void k_p4(unsigned* out) {
+    DECL unsigned c1, c2, c3;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P4BODY(c, 0) P4BODY(c1, 1) P4BODY(c2, 2) P4BODY(c3, 3)
+                     : COMMON_OUT, [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc");
+    }
+    FIN
+}
+// P5: P4 with the rank store deferred: ranks packed four to an SGPR (s_lshl_b32 + s_or_b32), none per step
+#define P5BODY(C) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 %[m0], 0x1fffff, vcc\n\ts_cbranch_scc0 1f\n\t1: s_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "s_lshl_b32 %[pk], %[pk], 8\n\ts_or_b32 %[pk], %[pk], %[i]\n\t"
+__global__ void k_p5(unsigned* out) {
+    DECL unsigned c1, c2, c3, pk = 0;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P5BODY(c) P5BODY(c1) P5BODY(c2) P5BODY(c3) "v_writelane_b32 %[ranks], %[pk], 0\n\t"
+                     : COMMON_OUT, [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [pk] "+s"(pk) : [v] "v"(v) : "vcc", "scc");
+    }
+    FIN
+}
+// P6: only the table chain (4 VALU + dpp), nothing else: the floor for this formulation
+#define P6BODY(C) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t"
+__global__ void k_p6(unsigned* out) {
+    DECL unsigned c1, c2, c3;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P6BODY(c) P6BODY(c1) P6BODY(c2) P6BODY(c3)
+                     : COMMON_OUT, [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc");
+    }
+    FIN
+}
+
+
+// P4NB: P4 without the branch (bound for any cleverer slow-path detection)
+#define P4NBBODY(C, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 %[m0], 0x1fffff, vcc\n\ts_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "v_writelane_b32 %[ranks], %[i], " #K "\n\t"
+__global__ void k_p4nb(unsigned* out) {
+    DECL unsigned c1, c2, c3;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P4NBBODY(c, 0) P4NBBODY(c1, 1) P4NBBODY(c2, 2) P4NBBODY(c3, 3)
+                     : COMMON_OUT, [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc");
+    }
+    FIN
+}
+// P7: scalar side work interleaved into the VALU chain
+#define P7BODY(C, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "s_andn2_b64 %[m0], 0x1fffff, vcc\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_ff1_i32_b64 %[i], %[m0]\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_cbranch_scc0 1f\n\t" \
+    "1: v_writelane_b32 %[ranks], %[i], " #K "\n\t"
+__global__ void k_p7(unsigned* out) {
+    DECL unsigned c1, c2, c3;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P7BODY(c, 0) P7BODY(c1, 1) P7BODY(c2, 2) P7BODY(c3, 3)
+                     : COMMON_OUT, [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc");
+    }
+    FIN
+}
+// P8: P7 with the rank store of step k-1 moved into step k (i alternates between two SGPRs)
+#define P8BODY(C, IP, IN, KPREV) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_writelane_b32 %[ranks], %[" #IP "], " #KPREV "\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "s_andn2_b64 %[m0], 0x1fffff, vcc\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_ff1_i32_b64 %[" #IN "], %[m0]\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_cbranch_scc0 1f\n\t1:\n\t"
+__global__ void k_p8(unsigned* out) {
+    DECL unsigned c1, c2, c3, i2 = 0; idx = 0;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P8BODY(c, i2, i, 3) P8BODY(c1, i, i2, 0) P8BODY(c2, i2, i, 1) P8BODY(c3, i, i2, 2)
+                     : [t0] "+v"(t0), [ranks] "+v"(ranks), [m0] "=&s"(m0), [m1] "=&s"(m1), [i] "+s"(idx), [i2] "+s"(i2), [c] "=&s"(c), [cv] "=&v"(cv), [up] "+v"(up),
+                       [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc");
+    }
+    FIN
+}
+// P9: P8 with the branch decided on the previous step's mask (one step late: s_cbranch far from its s_andn2)
+//     -- only a timing probe for "how much does distance to the branch matter"
+#define P9BODY(C, IP, IN, KPREV) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_writelane_b32 %[ranks], %[" #IP "], " #KPREV "\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "s_cbranch_scc0 1f\n\t1:\n\t" \
+    "s_andn2_b64 %[m0], 0x1fffff, vcc\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_ff1_i32_b64 %[" #IN "], %[m0]\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t"
+__global__ void k_p9(unsigned* out) {
+    DECL unsigned c1, c2, c3, i2 = 0; idx = 0;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("s_cmp_eq_u32 0, 0\n\tv_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P9BODY(c, i2, i, 3) P9BODY(c1, i, i2, 0) P9BODY(c2, i2, i, 1) P9BODY(c3, i, i2, 2)
+                     : [t0] "+v"(t0), [ranks] "+v"(ranks), [m0] "=&s"(m0), [m1] "=&s"(m1), [i] "+s"(idx), [i2] "+s"(i2), [c] "=&s"(c), [cv] "=&v"(cv), [up] "+v"(up),
+                       [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc");
+    }
+    FIN
+}
+
+template <class F> static double run(F launch) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int r = 0; r < 3; r++) {
+        (void)hipEventRecord(a); launch(); (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+        float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    return best;
+}
+int main(int argc, char** argv) {
+    setvbuf(stdout, NULL, _IONBF, 0);
+    int sel = argc > 1 ? atoi(argv[1]) : -1, kid = 0;
+    unsigned* out; (void)hipMalloc(&out, 4096);
+    unsigned h[64];
+    auto rep = [&](const char* name, double ms) {
+        (void)hipMemcpy(h, out, 256, hipMemcpyDeviceToHost);
+        unsigned cs = 0; for (int i = 0; i < 64; i++) cs = cs * 1000003u + h[i];
+        printf("%-44s %8.3f ms  %6.2f ns/step  checksum %08x\n", name, ms, ms * 1e6 / (4.0 * ITER), cs);
+    };
+#define RUN(NAME, K) if (sel < 0 || sel == kid) { rep(NAME, run([&] { K<<<1, 64>>>(out); })); } kid++;
+    RUN("P0 shipped (11)", k_p0)
+    RUN("P0 no cmp/branch (9)", k_p0nb)
+    RUN("P0 no rank store (10)", k_p0ns)
+    RUN("P2 all-VALU chain (11)", k_p2)
+    RUN("P3 P2 + andn2 branch (10)", k_p3)
+    RUN("P4 P3 + hoisted readlanes (10)", k_p4)
+    RUN("P5 P4 + packed ranks (11.25)", k_p5)
+    RUN("P6 chain only (6)", k_p6)
+    RUN("P4NB P4 without branch (9)", k_p4nb)
+    RUN("P7 interleaved scalar side (10)", k_p7)
+    RUN("P8 P7 + late rank store (10)", k_p8)
+    RUN("P9 P8 + branch one step late (10)", k_p9)
+    return 0;
+}
