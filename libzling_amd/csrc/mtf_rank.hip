@@ -202,84 +202,110 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
     }
 
 // Full tiles use a tighter form of the same step, shaped by scripts/ubench/mtfstep.hip (one lone wavefront on
-// gfx950: the shipped order above costs 32 ns/step, this one 25 ns): the table chain never leaves the vector
-// unit -- up[l] = t0[l+1] (DPP wave_shl:1), "c sits one lane up" = v_cmp_eq(c, up) replaces s_not + s_lshr, and
-// the value that lane takes is up itself, so c is only ever a scalar operand (no v_mov) -- the slow-path branch
-// hangs off ONE s_andn2 of vcc with the lane 0..20 mask (SCC = "hit in the fast lanes"), vector and scalar
-// instructions stay grouped (interleaving them measured slower), and eight literals are fetched by eight
-// back-to-back v_readlane in front of their steps.  up's lane 63 is never written (no lane 64 to read): it keeps
-// 0xFFFFFFFF, which no literal equals.
+// gfx950 issues ~2.2 ns per independent and ~3.5 ns per dependent instruction, a not-taken branch costs ~6 ns next
+// to its SCC producer, and alternating VALU/SALU is slower than grouping them; the shipped order above measures
+// 32 ns/step there, this one 20.6 ns):
+//   * the table chain never leaves the vector unit: up[l] = t0[l+1] (DPP wave_shl:1), "c sits one lane up" is
+//     v_cmp_eq(c, up) instead of s_not + s_lshr, and the value that lane takes is up itself, so c is only ever a
+//     scalar operand (no v_mov).  up's lane 63 is never written (no lane 64 to read): it keeps 0xFFFFFFFF, which
+//     no literal equals;
+//   * "hit in lanes 0..20" is ONE s_andn2 of vcc with the lane mask (SCC), and its one-hot low word is what the
+//     step records (v_writelane) -- the rank is decoded for all 64 lanes at once after the tile (v_ffbl);
+//   * the branch on that SCC is taken one step LATE, after the next step's three read-only instructions and before
+//     its two selects, so it never waits for its producer.  The out-of-line part of step K therefore finds t0 as
+//     step K left it, repairs it, and re-enters step K+1 at its top;
+//   * eight literals are fetched by eight back-to-back v_readlane in front of their steps, into register sets A/B
+//     alternately (a late out-of-line part still needs the previous group's literal).
+// Everything is one asm statement: an asm goto with outputs crashes this compiler's instruction selection, and SCC
+// cannot be carried between statements.  s[98:99] is the scratch pair whose low half v_writelane reads (an inline
+// asm operand cannot name half of a 64-bit operand).
 // DPP hazard (gfx9: VALU write -> DPP read of the same VGPR needs 2 wait states): t0's last VALU writer is the
-// previous step's second select, followed by s_andn2 / s_cbranch / s_ff1 / v_writelane; the slow path ends in s_nop 1.
-// One statement covers eight literals (an asm goto with outputs crashes this compiler's instruction selection,
-// and a C-level branch per step costs one more scalar instruction): a step whose hit is not in lanes 0..20
-// jumps to the end of the statement with its (empty) fast-lane mask in m0; the C code after the statement finds
-// the step from the first rank lane still holding the tile's 0xFFFFFFFF fill, replays that literal on the slow
-// path and the rest of the group with ZLNG_MTF_STEP.
-#define ZLNG_MTF_G_STEP(C, K)                                                                                   \
+// previous step's second select, followed by s_andn2 / v_writelane(ranks); the out-of-line part ends in
+// v_writelane(ranks) / s_cmp / s_branch.
+#define ZLNG_MTF_G_STEP(C, K, CP, KP)                                                                           \
+    "2" #K ":\n\t"                                                                                              \
     "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                      \
     "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t"                                                                \
     "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t"                                                              \
+    "s_cbranch_scc0 1" #KP "f\n\t"                                                                              \
     "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                      \
     "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t"                                                          \
-    "s_andn2_b64 %[hm], 0x1fffff, vcc\n\t"                                                                      \
-    "s_cbranch_scc0 1" #K "f\n\t"                                                                               \
-    "s_ff1_i32_b64 %[i], %[hm]\n\t"                                                                             \
-    "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
-    "2" #K ":\n\t"
-// Out-of-line part of step K (all 64 sit behind the 64 steps): the hit was not in lanes 0..20.
-//   rank 21..63: the step has already swapped c with its left neighbour; from that state the reference's
-//     swap(table[rank], table[mtfnext[rank]]) is  t0[rank-1] = t0[rank];  t0[rank] = t0[next];  t0[next] = c
-//     (next <= rank - 2 from rank 21 on, so t0[next] is untouched).  mtfnext = (rank * 62263) >> 16 below 128.
-//   rank >= 64 (c not in t0, nothing was changed): leave the statement with hm = 0.
-// v_readlane / v_writelane lane selects come from SALU results or M0 (no wait states owed); the closing s_nop
-// covers the v_writelane -> DPP read of t0 in the next step.
-#define ZLNG_MTF_G_SLOW(C, K)                                                                                   \
+    "s_andn2_b64 s[98:99], 0x1fffff, vcc\n\t"                                                                   \
+    "v_writelane_b32 %[ranks], s98, " #K "\n\t"
+// Out-of-line part of step K (all 64 sit behind the steps; entered from inside step KN = K + 1): c was not in
+// lanes 0..20.
+//   rank 21..63: the step has already swapped c with its left neighbour, so c is at lane rank - 1; from that state
+//     the reference's swap(table[rank], table[mtfnext[rank]]) is
+//         t0[rank-1] = t0[rank];  t0[rank] = t0[next];  t0[next] = c
+//     (next <= rank - 2 from rank 21 on, so t0[next] is untouched); mtfnext = (rank * 62263) >> 16 below 128.
+//     The rank is recorded as 0x80000000 | rank.
+//   rank >= 64 (c not in t0, nothing was changed): leave the statement with lv = 1; lane K of ranks holds 0.
+// v_readlane / v_writelane lane selects come from SALU results or M0 (no wait states owed).  SCC is set again
+// before re-entering step KN, whose late branch is evaluated a second time.
+#define ZLNG_MTF_G_SLOW(C, K, KN)                                                                               \
     "1" #K ":\n\t"                                                                                              \
-    "s_not_b64 %[hm], vcc\n\t"                                                                                  \
-    "s_cbranch_scc0 9f\n\t"                                                                                     \
-    "s_ff1_i32_b64 %[i], %[hm]\n\t"                                                                             \
+    "v_cmp_eq_u32_e64 s[98:99], %[" #C "], %[t0]\n\t"                                                           \
+    "s_cmp_eq_u64 s[98:99], 0\n\t"                                                                              \
+    "s_cbranch_scc1 8f\n\t"                                                                                     \
+    "s_ff1_i32_b64 %[nx], s[98:99]\n\t"                                                                         \
+    "s_add_u32 %[i], %[nx], 1\n\t"                                                                              \
+    "v_readlane_b32 %[d], %[t0], %[i]\n\t"                                                                      \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
     "s_mul_i32 %[nx], %[i], 0xf337\n\t"                                                                         \
     "s_lshr_b32 %[nx], %[nx], 16\n\t"                                                                           \
-    "v_readlane_b32 %[d], %[t0], %[i]\n\t"                                                                      \
-    "s_sub_u32 m0, %[i], 1\n\t"                                                                                 \
-    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
     "v_readlane_b32 %[d], %[t0], %[nx]\n\t"                                                                     \
     "s_mov_b32 m0, %[i]\n\t"                                                                                    \
     "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
     "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
     "v_writelane_b32 %[t0], %[" #C "], m0\n\t"                                                                  \
+    "s_or_b32 %[i], %[i], 0x80000000\n\t"                                                                       \
     "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
-    "s_nop 1\n\t"                                                                                               \
-    "s_branch 2" #K "b\n\t"
-#define ZLNG_MTF_G8(M, A, B, C, D, E, F, G, H) M(c0, A) M(c1, B) M(c2, C) M(c3, D) M(c4, E) M(c5, F) M(c6, G) M(c7, H)
-#define ZLNG_MTF_G_FETCH(A, B, C, D, E, F, G, H)                                                                \
-    "v_readlane_b32 %[c0], %[v], " #A "\n\tv_readlane_b32 %[c1], %[v], " #B "\n\t"                              \
-    "v_readlane_b32 %[c2], %[v], " #C "\n\tv_readlane_b32 %[c3], %[v], " #D "\n\t"                              \
-    "v_readlane_b32 %[c4], %[v], " #E "\n\tv_readlane_b32 %[c5], %[v], " #F "\n\t"                              \
-    "v_readlane_b32 %[c6], %[v], " #G "\n\tv_readlane_b32 %[c7], %[v], " #H "\n\t"
-#define ZLNG_MTF_G_FAST(A, B, C, D, E, F, G, H) ZLNG_MTF_G_FETCH(A, B, C, D, E, F, G, H) ZLNG_MTF_G8(ZLNG_MTF_G_STEP, A, B, C, D, E, F, G, H)
-// (A slow part runs before its group's successor fetches c0..c7 again, so its literal is still in its register.)
+    "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
+    "s_branch 2" #KN "b\n\t"
+#define ZLNG_MTF_G_FETCH(S, A, B, C, D, E, F, G, H)                                                             \
+    "v_readlane_b32 %[" #S "0], %[v], " #A "\n\tv_readlane_b32 %[" #S "1], %[v], " #B "\n\t"                    \
+    "v_readlane_b32 %[" #S "2], %[v], " #C "\n\tv_readlane_b32 %[" #S "3], %[v], " #D "\n\t"                    \
+    "v_readlane_b32 %[" #S "4], %[v], " #E "\n\tv_readlane_b32 %[" #S "5], %[v], " #F "\n\t"                    \
+    "v_readlane_b32 %[" #S "6], %[v], " #G "\n\tv_readlane_b32 %[" #S "7], %[v], " #H "\n\t"
+// group of eight steps: S = this group's literal set, SP = the previous group's, Z = the step before A
+#define ZLNG_MTF_G_FAST(S, SP, Z, A, B, C, D, E, F, G, H)                                                       \
+    ZLNG_MTF_G_FETCH(S, A, B, C, D, E, F, G, H)                                                                 \
+    ZLNG_MTF_G_STEP(S##0, A, SP##7, Z) ZLNG_MTF_G_STEP(S##1, B, S##0, A) ZLNG_MTF_G_STEP(S##2, C, S##1, B)      \
+    ZLNG_MTF_G_STEP(S##3, D, S##2, C)  ZLNG_MTF_G_STEP(S##4, E, S##3, D) ZLNG_MTF_G_STEP(S##5, F, S##4, E)      \
+    ZLNG_MTF_G_STEP(S##6, G, S##5, F)  ZLNG_MTF_G_STEP(S##7, H, S##6, G)
+#define ZLNG_MTF_G_COLD(S, A, B, C, D, E, F, G, H, N)                                                           \
+    ZLNG_MTF_G_SLOW(S##0, A, B) ZLNG_MTF_G_SLOW(S##1, B, C) ZLNG_MTF_G_SLOW(S##2, C, D) ZLNG_MTF_G_SLOW(S##3, D, E) \
+    ZLNG_MTF_G_SLOW(S##4, E, F) ZLNG_MTF_G_SLOW(S##5, F, G) ZLNG_MTF_G_SLOW(S##6, G, H) ZLNG_MTF_G_SLOW(S##7, H, N)
 
-// A whole 64-literal tile in ONE statement.  hm == 0 afterwards: a literal of rank >= 64 stopped it; the first
-// rank lane still holding the tile's 0xFFFFFFFF fill is that literal.
+// A whole 64-literal tile.  Labels: 2K = top of step K, 1K = out-of-line part of step K, 264 = after step 63,
+// 8 = leave, 9 = end.  Step 0 has no predecessor: SCC is set on entry and its branch (to any label) is never taken.
 #define ZLNG_MTF_TILE()                                                                                         \
     asm volatile(                                                                                               \
-        ZLNG_MTF_G_FAST(0, 1, 2, 3, 4, 5, 6, 7)         ZLNG_MTF_G_FAST(8, 9, 10, 11, 12, 13, 14, 15)           \
-        ZLNG_MTF_G_FAST(16, 17, 18, 19, 20, 21, 22, 23) ZLNG_MTF_G_FAST(24, 25, 26, 27, 28, 29, 30, 31)         \
-        ZLNG_MTF_G_FAST(32, 33, 34, 35, 36, 37, 38, 39) ZLNG_MTF_G_FAST(40, 41, 42, 43, 44, 45, 46, 47)         \
-        ZLNG_MTF_G_FAST(48, 49, 50, 51, 52, 53, 54, 55) ZLNG_MTF_G_FAST(56, 57, 58, 59, 60, 61, 62, 63)         \
+        "s_cmp_eq_u32 0, 0\n\t"                                                                                 \
+        ZLNG_MTF_G_FAST(ca, cb, 19, 0, 1, 2, 3, 4, 5, 6, 7)         ZLNG_MTF_G_FAST(cb, ca, 7, 8, 9, 10, 11, 12, 13, 14, 15)   \
+        ZLNG_MTF_G_FAST(ca, cb, 15, 16, 17, 18, 19, 20, 21, 22, 23) ZLNG_MTF_G_FAST(cb, ca, 23, 24, 25, 26, 27, 28, 29, 30, 31) \
+        ZLNG_MTF_G_FAST(ca, cb, 31, 32, 33, 34, 35, 36, 37, 38, 39) ZLNG_MTF_G_FAST(cb, ca, 39, 40, 41, 42, 43, 44, 45, 46, 47) \
+        ZLNG_MTF_G_FAST(ca, cb, 47, 48, 49, 50, 51, 52, 53, 54, 55) ZLNG_MTF_G_FAST(cb, ca, 55, 56, 57, 58, 59, 60, 61, 62, 63) \
+        "264:\n\t"                                                                                              \
+        "s_cbranch_scc0 163f\n\t"                                                                               \
+        "s_mov_b32 %[lv], 0\n\t"                                                                                \
         "s_branch 9f\n\t"                                                                                       \
-        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 0, 1, 2, 3, 4, 5, 6, 7)         ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 8, 9, 10, 11, 12, 13, 14, 15)   \
-        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 16, 17, 18, 19, 20, 21, 22, 23) ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 24, 25, 26, 27, 28, 29, 30, 31) \
-        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 32, 33, 34, 35, 36, 37, 38, 39) ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 40, 41, 42, 43, 44, 45, 46, 47) \
-        ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 48, 49, 50, 51, 52, 53, 54, 55) ZLNG_MTF_G8(ZLNG_MTF_G_SLOW, 56, 57, 58, 59, 60, 61, 62, 63) \
+        ZLNG_MTF_G_COLD(ca, 0, 1, 2, 3, 4, 5, 6, 7, 8)          ZLNG_MTF_G_COLD(cb, 8, 9, 10, 11, 12, 13, 14, 15, 16)     \
+        ZLNG_MTF_G_COLD(ca, 16, 17, 18, 19, 20, 21, 22, 23, 24) ZLNG_MTF_G_COLD(cb, 24, 25, 26, 27, 28, 29, 30, 31, 32)   \
+        ZLNG_MTF_G_COLD(ca, 32, 33, 34, 35, 36, 37, 38, 39, 40) ZLNG_MTF_G_COLD(cb, 40, 41, 42, 43, 44, 45, 46, 47, 48)   \
+        ZLNG_MTF_G_COLD(ca, 48, 49, 50, 51, 52, 53, 54, 55, 56) ZLNG_MTF_G_COLD(cb, 56, 57, 58, 59, 60, 61, 62, 63, 64)   \
+        "8:\n\t"                                                                                                \
+        "s_mov_b32 %[lv], 1\n\t"                                                                                \
         "9:"                                                                                                    \
-        : [t0] "+v"(t0), [up] "+v"(up), [ranks] "+v"(ranks), [hm] "=&s"(hm_), [m1] "=&s"(m1_), [i] "=&s"(i_),   \
-          [nx] "=&s"(nx_), [d] "=&s"(d_), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3),       \
-          [c4] "=&s"(c4), [c5] "=&s"(c5), [c6] "=&s"(c6), [c7] "=&s"(c7)                                        \
+        : [t0] "+v"(t0), [up] "+v"(up), [ranks] "+v"(ranks), [m1] "=&s"(m1_), [i] "=&s"(i_), [nx] "=&s"(nx_),   \
+          [d] "=&s"(d_), [lv] "=&s"(lv_),                                                                       \
+          [ca0] "=&s"(ca0), [ca1] "=&s"(ca1), [ca2] "=&s"(ca2), [ca3] "=&s"(ca3), [ca4] "=&s"(ca4),             \
+          [ca5] "=&s"(ca5), [ca6] "=&s"(ca6), [ca7] "=&s"(ca7), [cb0] "=&s"(cb0), [cb1] "=&s"(cb1),             \
+          [cb2] "=&s"(cb2), [cb3] "=&s"(cb3), [cb4] "=&s"(cb4), [cb5] "=&s"(cb5), [cb6] "=&s"(cb6),             \
+          [cb7] "=&s"(cb7)                                                                                      \
         : [v] "v"(v)                                                                                            \
-        : "vcc", "scc")
+        : "vcc", "scc", "s98", "s99")
 
 __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     const uint32_t ctx = blockIdx.x;
@@ -311,12 +337,14 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
         vnext = nidx < n ? (uint32_t)run[nidx] : 0u;                   // next tile in flight while this one is replayed
         uint32_t ranks = 0xFFFFFFFFu;
         if (base + 64 <= n) {
-            uint32_t c0, c1, c2, c3, c4, c5, c6, c7, i_, nx_, d_;
-            uint64_t hm_, m1_;
+            uint32_t ca0, ca1, ca2, ca3, ca4, ca5, ca6, ca7, cb0, cb1, cb2, cb3, cb4, cb5, cb6, cb7, i_, nx_, d_, lv_;
+            uint64_t m1_;
             ZLNG_MTF_TILE();
-            if (__builtin_expect(hm_ == 0, 0)) {
+            const uint32_t rec = ranks;                                  // one-hot word, 0x80000000 | rank, 0 or the fill
+            ranks = (rec & 0x80000000u) ? (rec & 0xFFu) : (uint32_t)__builtin_ctz(rec | 0x40000000u);
+            if (__builtin_expect(lv_ != 0, 0)) {                         // a literal of rank >= 64 stopped the statement
 #define RANKSTORE(I, K) wrl(ranks, I, K)
-                const uint32_t kk = (uint32_t)__builtin_ctzll(__ballot(ranks == 0xFFFFFFFFu));
+                const uint32_t kk = (uint32_t)__builtin_ctzll(__ballot(rec == 0u));
                 const uint32_t r = slow_step(rdl(v, kk));
                 wrl(ranks, r, kk);
                 for (uint32_t k = kk + 1; k < 64u; k++) ZLNG_MTF_STEP(k)

@@ -194,6 +194,47 @@ __global__ void k_p9(unsigned* out) {
     FIN
 }
 
+
+// P10: P4 with the rank recorded as the one-hot fast-lane mask (v_writelane of hm_lo), decoded per tile later
+#define P10BODY(C, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\ts_cbranch_scc0 1f\n\t1: " \
+    "v_writelane_b32 %[ranks], s90, " #K "\n\t"
+__global__ void k_p10(unsigned* out) {
+    DECL unsigned c1, c2, c3;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P10BODY(c, 0) P10BODY(c1, 1) P10BODY(c2, 2) P10BODY(c3, 3)
+                     : [t0] "+v"(t0), [ranks] "+v"(ranks), [m0] "=&s"(m0), [m1] "=&s"(m1), [c] "=&s"(c), [cv] "=&v"(cv), [up] "+v"(up),
+                       [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc", "s90", "s91");
+    }
+    FIN
+}
+// P11: P10 with the branch of step k-1 taken inside step k, after its compares (SCC carried across the VALU ops)
+#define P11BODY(C, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t" \
+    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t" \
+    "s_cbranch_scc0 1f\n\t1: " \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t" \
+    "v_writelane_b32 %[ranks], s90, " #K "\n\t"
+__global__ void k_p11(unsigned* out) {
+    DECL unsigned c1, c2, c3;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("s_cmp_eq_u32 0, 0\n\tv_readlane_b32 %[c], %[v], 0\n\tv_readlane_b32 %[c1], %[v], 1\n\tv_readlane_b32 %[c2], %[v], 2\n\tv_readlane_b32 %[c3], %[v], 3\n\t"
+                     P11BODY(c, 0) P11BODY(c1, 1) P11BODY(c2, 2) P11BODY(c3, 3)
+                     : [t0] "+v"(t0), [ranks] "+v"(ranks), [m0] "=&s"(m0), [m1] "=&s"(m1), [c] "=&s"(c), [cv] "=&v"(cv), [up] "+v"(up),
+                       [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3) : [v] "v"(v) : "vcc", "scc", "s90", "s91");
+    }
+    FIN
+}
+
 template <class F> static double run(F launch) {
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     float best = 1e30f;
@@ -226,5 +267,7 @@ int main(int argc, char** argv) {
     RUN("P7 interleaved scalar side (10)", k_p7)
     RUN("P8 P7 + late rank store (10)", k_p8)
     RUN("P9 P8 + branch one step late (10)", k_p9)
+    RUN("P10 P4 + one-hot rank record (9)", k_p10)
+    RUN("P11 P10 + late branch (9)", k_p11)
     return 0;
 }
