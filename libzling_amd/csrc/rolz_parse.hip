@@ -49,13 +49,20 @@ __device__ __forceinline__ int common_len(const uint8_t* a, const uint8_t* b) {
     return n;
 }
 
+// One context's dictionary plane.  Fields are addressed as (wave-uniform base) + (32-bit byte offset): the whole
+// per-block dictionary is 10 MiB, so the offset fits a VGPR and every access is a global_load/store with an SGPR
+// base ("saddr") -- no 64-bit per-lane pointer arithmetic.
+template <class T> struct BktField {
+    uint8_t* d; uint32_t o;
+    __device__ __forceinline__ T& operator[](uint32_t i) const { return *reinterpret_cast<T*>(d + (o + (uint32_t)sizeof(T) * i)); }
+};
 struct Bucket {
-    uint32_t* offset; uint16_t* suffix; uint16_t* hash;
+    BktField<uint32_t> offset; BktField<uint16_t> suffix; BktField<uint16_t> hash;
     __device__ __forceinline__ Bucket(uint8_t* dict, uint32_t ctx) {
-        uint8_t* b = dict + (size_t)ctx * kBktBytes;
-        offset = reinterpret_cast<uint32_t*>(b + kBktOffsetOff);
-        suffix = reinterpret_cast<uint16_t*>(b + kBktSuffixOff);
-        hash   = reinterpret_cast<uint16_t*>(b + kBktHashOff);
+        const uint32_t b = ctx * kBktBytes;
+        offset = {dict, b + kBktOffsetOff};
+        suffix = {dict, b + kBktSuffixOff};
+        hash   = {dict, b + kBktHashOff};
     }
 };
 
@@ -393,7 +400,7 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
 __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
                                              uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t head0 = heads[ctx];
-    const Quad qa = ld128u(buf + pos);
+    const Quad qa = ld128u(buf + (uint32_t)pos);
     const uint32_t lctx1 = w4 & 0xFF;
     const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
     Bucket B(dict, ctx), B1(dict, lctx1);
@@ -434,7 +441,7 @@ __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8
     // round trip 5: the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1)
     const bool lz1 = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
     const uint32_t m = lz1 ? maxlen - 3u : 0u;
-    const uint32_t probe = ld32u(buf + pos + 1 + m);
+    const uint32_t probe = ld32u(buf + ((uint32_t)pos + 1u + m));
     const uint32_t srcw = ld32u(buf + ((lz1 && hasl) ? (lov1 & 0xFFFFFF) + m : (uint32_t)pos));
     if (lz1 && hasl && probe == srcw) sp |= kSpVeto1;
     if (hasl && ring_dist(ln1, lhead1) < kRiskDist) sp |= kSpRisk1;      // (kept even when no probe was needed: the conflict fix may need one)
@@ -452,6 +459,10 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// kAllL0: every sub-block of the batch runs at level 0 (always true for an e0 context, whose schedule cannot
+// change): the generic speculation and the level tests drop out of the kernel.
+// kProf: cycle counters into a.dbg (ZLNG_PROFILE=1); compiled out of the production kernels.
+template <bool kAllL0, bool kProf>
 __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     __shared__ uint16_t heads[256];
     __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
@@ -491,13 +502,13 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             if (__atomic_load_n(&pf_done, __ATOMIC_RELAXED)) break;
             int start = P + 64 > done_to ? P + 64 : done_to;
             if (start >= P + 64 + 128 || start >= ilen) { __builtin_amdgcn_s_sleep(16); continue; }
-            const LevelCfg pcfg = level_cfg(__atomic_load_n(&pf_level, __ATOMIC_RELAXED));
+            const LevelCfg pcfg = kAllL0 ? level_cfg(0) : level_cfg(__atomic_load_n(&pf_level, __ATOMIC_RELAXED));
             const int pos = start + lane;
             if (pos >= 4 && pos + kSentinel < ilen) {
                 const uint32_t wpp = ld32u(buf + pos - 4), w4p = ld32u(buf + pos);
                 const uint32_t hp = hash_of(w4p);
                 Spec S;
-                if (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0) speculate_l0(S, dict, buf, heads, pos, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) speculate_l0(S, dict, buf, heads, pos, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 else speculate(S, dict, buf, heads, pos, pcfg, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
             }
@@ -510,12 +521,12 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     int q = 0, nsub = 0;
     unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
     unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0;
-    const bool prof = a.dbg != nullptr;
+    const bool prof = kProf && a.dbg != nullptr;
 
     while (q < ilen) {                               // ---- one sub-block (one EncodeImpl call)
-        const LevelCfg cfg = level_cfg(a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)]);
+        const LevelCfg cfg = kAllL0 ? level_cfg(0) : level_cfg(a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)]);
         if (lane == 0) __atomic_store_n(&pf_level, (int)a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)], __ATOMIC_RELAXED);
-        const bool level0 = cfg.depth == 2 && cfg.lazy1 == 1 && cfg.lazy2 == 0;
+        const bool level0 = kAllL0 || (cfg.depth == 2 && cfg.lazy1 == 1 && cfg.lazy2 == 0);
         const uint32_t tok_begin = nt;
         int opos = 0;
         uint32_t prevty = kTyNone;                   // kind of the token that ended at q (none: MRU starts empty)
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             const bool canm = pos + kSentinel < ilen;
             uint32_t wp, w4 = 0;
             if (pos >= 4) wp = ld32u(buf + pos - 4); else wp = ld32u(buf) << (8 * (4 - pos));
-            if (live) w4 = ld32u(buf + pos);
+            if (live) w4 = ld32u(buf + (uint32_t)pos);
             const uint32_t ctx = wp >> 24;
             const uint32_t h = hash_of(w4);
             const uint32_t hc = h % kHashSlots, chk = (h / kHashSlots) & 255u;
@@ -853,8 +864,12 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     }
 }
 
-void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_rolz_parse_wave, dim3(nblocks), dim3(128), 0, s, a);
+void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0) {
+    const bool prof = a.dbg != nullptr;
+    if (all_level0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wave<true, false>), dim3(nblocks), dim3(128), 0, s, a);
+    else if (all_level0) hipLaunchKernelGGL((k_rolz_parse_wave<true, true>), dim3(nblocks), dim3(128), 0, s, a);
+    else if (!prof) hipLaunchKernelGGL((k_rolz_parse_wave<false, false>), dim3(nblocks), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((k_rolz_parse_wave<false, true>), dim3(nblocks), dim3(128), 0, s, a);
 }
 
 }  // namespace zlng

@@ -154,7 +154,7 @@ int ensure_out(zlng_ctx* c, size_t bytes) {
 
 void launch_parse(zlng_ctx* c, const ParseArgs& pa, uint32_t nb) {
     if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
-    else launch_rolz_parse_wave(pa, nb, c->stream);
+    else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
 }
 
 // Parse + rank + histogram + lengths for nb blocks under the current level schedule; repeats

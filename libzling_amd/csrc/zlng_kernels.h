@@ -19,7 +19,7 @@ struct ParseArgs {
 };
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s);
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
-void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
+void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);
 
 // ---- K2 ------------------------------------------------------------------------------
 struct MtfArgs {

@@ -235,6 +235,27 @@ __global__ void k_p11(unsigned* out) {
     FIN
 }
 
+
+// P12: P11 with the literal taken as a byte of a packed SGPR (SDWA scalar source): no per-literal fetch at all
+#define P12BODY(B, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_sdwa vcc, %[pk], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "v_cmp_eq_u32_sdwa %[m1], %[pk], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "s_cbranch_scc0 1f\n\t1: " \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t" \
+    "v_writelane_b32 %[ranks], s90, " #K "\n\t"
+__global__ void k_p12(unsigned* out) {
+    DECL unsigned pk = 0x0d060a03u;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("s_cmp_eq_u32 0, 0\n\t"
+                     P12BODY(0, 0) P12BODY(1, 1) P12BODY(2, 2) P12BODY(3, 3)
+                     : [t0] "+v"(t0), [ranks] "+v"(ranks), [m1] "=&s"(m1), [up] "+v"(up) : [pk] "s"(pk) : "vcc", "scc", "s90", "s91");
+    }
+    FIN
+}
+
 template <class F> static double run(F launch) {
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     float best = 1e30f;
@@ -269,5 +290,6 @@ int main(int argc, char** argv) {
     RUN("P9 P8 + branch one step late (10)", k_p9)
     RUN("P10 P4 + one-hot rank record (9)", k_p10)
     RUN("P11 P10 + late branch (9)", k_p11)
+    RUN("P12 P11 + SDWA packed literals (8)", k_p12)
     return 0;
 }
