@@ -342,9 +342,9 @@ __device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, i
 }
 
 __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
-                                          const LevelCfg cfg, uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
+                                          const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t head0 = heads[ctx];
-    const Quad qa = ld128u(buf + pos);               // bytes pos .. pos+15 (pos+275 < ilen)
+    const uint32_t w4 = qa.a;                        // qa: bytes pos .. pos+15, loaded by the caller (pos+275 < ilen)
     const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
     const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
     const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
@@ -398,9 +398,9 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
 // the level the benchmark runs the generic form spends most of phase 1 on control flow rather than on the
 // five dependent memory round trips.  Only the >16-byte tail of a long match keeps a (wave-uniform) loop.
 __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, const uint16_t* heads, int pos,
-                                             uint32_t w4, uint32_t ctx, uint32_t hc, uint32_t chk) {
+                                             const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t head0 = heads[ctx];
-    const Quad qa = ld128u(buf + (uint32_t)pos);
+    const uint32_t w4 = qa.a;
     const uint32_t lctx1 = w4 & 0xFF;
     const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
     Bucket B(dict, ctx), B1(dict, lctx1);
@@ -505,11 +505,12 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             const LevelCfg pcfg = kAllL0 ? level_cfg(0) : level_cfg(__atomic_load_n(&pf_level, __ATOMIC_RELAXED));
             const int pos = start + lane;
             if (pos >= 4 && pos + kSentinel < ilen) {
-                const uint32_t wpp = ld32u(buf + pos - 4), w4p = ld32u(buf + pos);
-                const uint32_t hp = hash_of(w4p);
+                const uint32_t wpp = ld32u(buf + pos - 4);
+                const Quad qap = ld128u(buf + (uint32_t)pos);
+                const uint32_t hp = hash_of(qap.a);
                 Spec S;
-                if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) speculate_l0(S, dict, buf, heads, pos, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
-                else speculate(S, dict, buf, heads, pos, pcfg, w4p, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) speculate_l0(S, dict, buf, heads, pos, qap, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                else speculate(S, dict, buf, heads, pos, pcfg, qap, wpp >> 24, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
             }
             done_to = start + 64;
@@ -549,9 +550,14 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             const int pos = P + lane;
             const bool live = pos < ilen;
             const bool canm = pos + kSentinel < ilen;
-            uint32_t wp, w4 = 0;
-            if (pos >= 4) wp = ld32u(buf + pos - 4); else wp = ld32u(buf) << (8 * (4 - pos));
-            if (live) w4 = ld32u(buf + (uint32_t)pos);
+            // one round trip for all of this position's text: bytes pos-4 .. pos-1 (context and MRU operands) and
+            // pos .. pos+15 (hashes of pos and pos+1, first compare block).  No lane guard: the window ends less than
+            // 80 bytes behind the block, inside the 512 readable bytes the boundary requires (include/zlng.h).
+            const uint32_t upos = (uint32_t)pos;
+            const uint32_t wraw = ld32u(buf + (upos >= 4u ? upos - 4u : 0u));
+            const Quad qtext = ld128u(buf + upos);
+            const uint32_t wp = upos >= 4u ? wraw : wraw << ((8u * (4u - upos)) & 31u);
+            const uint32_t w4 = live ? qtext.a : 0u;
             const uint32_t ctx = wp >> 24;
             const uint32_t h = hash_of(w4);
             const uint32_t hc = h % kHashSlots, chk = (h / kHashSlots) & 255u;
@@ -570,8 +576,8 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             if (canm) {
                 atomicOr(&keytab[kix], lane_bit);
                 atomicOr(&ctxtab[ctx], lane_bit);
-                if (level0) speculate_l0(S, dict, buf, heads, pos, w4, ctx, hc, chk);
-                else speculate(S, dict, buf, heads, pos, cfg, w4, ctx, hc, chk);
+                if (level0) speculate_l0(S, dict, buf, heads, pos, qtext, ctx, hc, chk);
+                else speculate(S, dict, buf, heads, pos, cfg, qtext, ctx, hc, chk);
             }
             const uint32_t sp = S.sp, node0 = S.node0, head0 = S.head0, dmin = S.dmin;
             const uint32_t lkix1 = S.lkix1, lkix2 = S.lkix2, lctx1 = S.lctx1, lctx2 = S.lctx2;
