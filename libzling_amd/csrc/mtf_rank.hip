@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void k_lit_scan(MtfArgs a) {
 __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
     const uint32_t lane = threadIdx.x;
     uint32_t v[4], s = 0;
-    for (int k = 0; k < 4; k++) { v[k] = a.ctx_total[lane * 4 + k]; s += v[k]; }
+    // every run starts on a 64-byte line: k_mtf_dense fetches whole tiles of 64 literals with one scalar load
+    for (int k = 0; k < 4; k++) { v[k] = (a.ctx_total[lane * 4 + k] + 63u) & ~63u; s += v[k]; }
     uint32_t incl = s;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += y; }
     uint32_t off = incl - s;
@@ -222,11 +223,14 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
 // DPP hazard (gfx9: VALU write -> DPP read of the same VGPR needs 2 wait states): t0's last VALU writer is the
 // previous step's second select, followed by s_andn2 / v_writelane(ranks); the out-of-line part ends in
 // v_writelane(ranks) / s_cmp / s_branch.
-#define ZLNG_MTF_G_STEP(C, K, CP, KP)                                                                           \
+// The 64 literals of a tile are never unpacked: the tile is sixteen SGPRs (one s_load_dwordx16, issued for the
+// NEXT tile at the top of the statement and awaited at its end) and each step compares byte K&3 of register K>>2
+// through an SDWA scalar source -- no per-literal fetch instruction at all (19.1 ns/step in the microbenchmark).
+#define ZLNG_MTF_G_STEP(PK, B, K, KP)                                                                           \
     "2" #K ":\n\t"                                                                                              \
     "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                      \
-    "v_cmp_ne_u32_e32 vcc, %[" #C "], %[t0]\n\t"                                                                \
-    "v_cmp_eq_u32_e64 %[m1], %[" #C "], %[up]\n\t"                                                              \
+    "v_cmp_ne_u32_sdwa vcc, %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
+    "v_cmp_eq_u32_sdwa %[m1], %[" #PK "], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                        \
     "s_cbranch_scc0 1" #KP "f\n\t"                                                                              \
     "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                      \
     "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t"                                                          \
@@ -242,9 +246,9 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
 //   rank >= 64 (c not in t0, nothing was changed): leave the statement with lv = 1; lane K of ranks holds 0.
 // v_readlane / v_writelane lane selects come from SALU results or M0 (no wait states owed).  SCC is set again
 // before re-entering step KN, whose late branch is evaluated a second time.
-#define ZLNG_MTF_G_SLOW(C, K, KN)                                                                               \
+#define ZLNG_MTF_G_SLOW(PK, B, K, KN)                                                                           \
     "1" #K ":\n\t"                                                                                              \
-    "v_cmp_eq_u32_e64 s[98:99], %[" #C "], %[t0]\n\t"                                                           \
+    "v_cmp_eq_u32_sdwa s[98:99], %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                     \
     "s_cmp_eq_u64 s[98:99], 0\n\t"                                                                              \
     "s_cbranch_scc1 8f\n\t"                                                                                     \
     "s_ff1_i32_b64 %[nx], s[98:99]\n\t"                                                                         \
@@ -258,53 +262,54 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
     "s_mov_b32 m0, %[i]\n\t"                                                                                    \
     "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
     "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
-    "v_writelane_b32 %[t0], %[" #C "], m0\n\t"                                                                  \
+    "s_bfe_u32 %[d], %[" #PK "], (8 * " #B ") | (8 << 16)\n\t"                                                  \
+    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
     "s_or_b32 %[i], %[i], 0x80000000\n\t"                                                                       \
     "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
     "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
     "s_branch 2" #KN "b\n\t"
-#define ZLNG_MTF_G_FETCH(S, A, B, C, D, E, F, G, H)                                                             \
-    "v_readlane_b32 %[" #S "0], %[v], " #A "\n\tv_readlane_b32 %[" #S "1], %[v], " #B "\n\t"                    \
-    "v_readlane_b32 %[" #S "2], %[v], " #C "\n\tv_readlane_b32 %[" #S "3], %[v], " #D "\n\t"                    \
-    "v_readlane_b32 %[" #S "4], %[v], " #E "\n\tv_readlane_b32 %[" #S "5], %[v], " #F "\n\t"                    \
-    "v_readlane_b32 %[" #S "6], %[v], " #G "\n\tv_readlane_b32 %[" #S "7], %[v], " #H "\n\t"
-// group of eight steps: S = this group's literal set, SP = the previous group's, Z = the step before A
-#define ZLNG_MTF_G_FAST(S, SP, Z, A, B, C, D, E, F, G, H)                                                       \
-    ZLNG_MTF_G_FETCH(S, A, B, C, D, E, F, G, H)                                                                 \
-    ZLNG_MTF_G_STEP(S##0, A, SP##7, Z) ZLNG_MTF_G_STEP(S##1, B, S##0, A) ZLNG_MTF_G_STEP(S##2, C, S##1, B)      \
-    ZLNG_MTF_G_STEP(S##3, D, S##2, C)  ZLNG_MTF_G_STEP(S##4, E, S##3, D) ZLNG_MTF_G_STEP(S##5, F, S##4, E)      \
-    ZLNG_MTF_G_STEP(S##6, G, S##5, F)  ZLNG_MTF_G_STEP(S##7, H, S##6, G)
-#define ZLNG_MTF_G_COLD(S, A, B, C, D, E, F, G, H, N)                                                           \
-    ZLNG_MTF_G_SLOW(S##0, A, B) ZLNG_MTF_G_SLOW(S##1, B, C) ZLNG_MTF_G_SLOW(S##2, C, D) ZLNG_MTF_G_SLOW(S##3, D, E) \
-    ZLNG_MTF_G_SLOW(S##4, E, F) ZLNG_MTF_G_SLOW(S##5, F, G) ZLNG_MTF_G_SLOW(S##6, G, H) ZLNG_MTF_G_SLOW(S##7, H, N)
+// four steps = one literal register: Z = the step before A
+#define ZLNG_MTF_G_FAST(PK, Z, A, B, C, D)                                                                      \
+    ZLNG_MTF_G_STEP(PK, 0, A, Z) ZLNG_MTF_G_STEP(PK, 1, B, A) ZLNG_MTF_G_STEP(PK, 2, C, B) ZLNG_MTF_G_STEP(PK, 3, D, C)
+#define ZLNG_MTF_G_COLD(PK, A, B, C, D, N)                                                                      \
+    ZLNG_MTF_G_SLOW(PK, 0, A, B) ZLNG_MTF_G_SLOW(PK, 1, B, C) ZLNG_MTF_G_SLOW(PK, 2, C, D) ZLNG_MTF_G_SLOW(PK, 3, D, N)
 
 // A whole 64-literal tile.  Labels: 2K = top of step K, 1K = out-of-line part of step K, 264 = after step 63,
 // 8 = leave, 9 = end.  Step 0 has no predecessor: SCC is set on entry and its branch (to any label) is never taken.
 #define ZLNG_MTF_TILE()                                                                                         \
     asm volatile(                                                                                               \
+        "s_load_dwordx16 %[nxt], %[ptr], 0x40\n\t"                                                              \
         "s_cmp_eq_u32 0, 0\n\t"                                                                                 \
-        ZLNG_MTF_G_FAST(ca, cb, 19, 0, 1, 2, 3, 4, 5, 6, 7)         ZLNG_MTF_G_FAST(cb, ca, 7, 8, 9, 10, 11, 12, 13, 14, 15)   \
-        ZLNG_MTF_G_FAST(ca, cb, 15, 16, 17, 18, 19, 20, 21, 22, 23) ZLNG_MTF_G_FAST(cb, ca, 23, 24, 25, 26, 27, 28, 29, 30, 31) \
-        ZLNG_MTF_G_FAST(ca, cb, 31, 32, 33, 34, 35, 36, 37, 38, 39) ZLNG_MTF_G_FAST(cb, ca, 39, 40, 41, 42, 43, 44, 45, 46, 47) \
-        ZLNG_MTF_G_FAST(ca, cb, 47, 48, 49, 50, 51, 52, 53, 54, 55) ZLNG_MTF_G_FAST(cb, ca, 55, 56, 57, 58, 59, 60, 61, 62, 63) \
+        ZLNG_MTF_G_FAST(p0, 19, 0, 1, 2, 3)      ZLNG_MTF_G_FAST(p1, 3, 4, 5, 6, 7)                             \
+        ZLNG_MTF_G_FAST(p2, 7, 8, 9, 10, 11)     ZLNG_MTF_G_FAST(p3, 11, 12, 13, 14, 15)                        \
+        ZLNG_MTF_G_FAST(p4, 15, 16, 17, 18, 19)  ZLNG_MTF_G_FAST(p5, 19, 20, 21, 22, 23)                        \
+        ZLNG_MTF_G_FAST(p6, 23, 24, 25, 26, 27)  ZLNG_MTF_G_FAST(p7, 27, 28, 29, 30, 31)                        \
+        ZLNG_MTF_G_FAST(p8, 31, 32, 33, 34, 35)  ZLNG_MTF_G_FAST(p9, 35, 36, 37, 38, 39)                        \
+        ZLNG_MTF_G_FAST(p10, 39, 40, 41, 42, 43) ZLNG_MTF_G_FAST(p11, 43, 44, 45, 46, 47)                       \
+        ZLNG_MTF_G_FAST(p12, 47, 48, 49, 50, 51) ZLNG_MTF_G_FAST(p13, 51, 52, 53, 54, 55)                       \
+        ZLNG_MTF_G_FAST(p14, 55, 56, 57, 58, 59) ZLNG_MTF_G_FAST(p15, 59, 60, 61, 62, 63)                       \
         "264:\n\t"                                                                                              \
         "s_cbranch_scc0 163f\n\t"                                                                               \
         "s_mov_b32 %[lv], 0\n\t"                                                                                \
         "s_branch 9f\n\t"                                                                                       \
-        ZLNG_MTF_G_COLD(ca, 0, 1, 2, 3, 4, 5, 6, 7, 8)          ZLNG_MTF_G_COLD(cb, 8, 9, 10, 11, 12, 13, 14, 15, 16)     \
-        ZLNG_MTF_G_COLD(ca, 16, 17, 18, 19, 20, 21, 22, 23, 24) ZLNG_MTF_G_COLD(cb, 24, 25, 26, 27, 28, 29, 30, 31, 32)   \
-        ZLNG_MTF_G_COLD(ca, 32, 33, 34, 35, 36, 37, 38, 39, 40) ZLNG_MTF_G_COLD(cb, 40, 41, 42, 43, 44, 45, 46, 47, 48)   \
-        ZLNG_MTF_G_COLD(ca, 48, 49, 50, 51, 52, 53, 54, 55, 56) ZLNG_MTF_G_COLD(cb, 56, 57, 58, 59, 60, 61, 62, 63, 64)   \
+        ZLNG_MTF_G_COLD(p0, 0, 1, 2, 3, 4)       ZLNG_MTF_G_COLD(p1, 4, 5, 6, 7, 8)                             \
+        ZLNG_MTF_G_COLD(p2, 8, 9, 10, 11, 12)    ZLNG_MTF_G_COLD(p3, 12, 13, 14, 15, 16)                        \
+        ZLNG_MTF_G_COLD(p4, 16, 17, 18, 19, 20)  ZLNG_MTF_G_COLD(p5, 20, 21, 22, 23, 24)                        \
+        ZLNG_MTF_G_COLD(p6, 24, 25, 26, 27, 28)  ZLNG_MTF_G_COLD(p7, 28, 29, 30, 31, 32)                        \
+        ZLNG_MTF_G_COLD(p8, 32, 33, 34, 35, 36)  ZLNG_MTF_G_COLD(p9, 36, 37, 38, 39, 40)                        \
+        ZLNG_MTF_G_COLD(p10, 40, 41, 42, 43, 44) ZLNG_MTF_G_COLD(p11, 44, 45, 46, 47, 48)                       \
+        ZLNG_MTF_G_COLD(p12, 48, 49, 50, 51, 52) ZLNG_MTF_G_COLD(p13, 52, 53, 54, 55, 56)                       \
+        ZLNG_MTF_G_COLD(p14, 56, 57, 58, 59, 60) ZLNG_MTF_G_COLD(p15, 60, 61, 62, 63, 64)                       \
         "8:\n\t"                                                                                                \
         "s_mov_b32 %[lv], 1\n\t"                                                                                \
-        "9:"                                                                                                    \
+        "9:\n\t"                                                                                                \
+        "s_waitcnt lgkmcnt(0)"                                                                                  \
         : [t0] "+v"(t0), [up] "+v"(up), [ranks] "+v"(ranks), [m1] "=&s"(m1_), [i] "=&s"(i_), [nx] "=&s"(nx_),   \
-          [d] "=&s"(d_), [lv] "=&s"(lv_),                                                                       \
-          [ca0] "=&s"(ca0), [ca1] "=&s"(ca1), [ca2] "=&s"(ca2), [ca3] "=&s"(ca3), [ca4] "=&s"(ca4),             \
-          [ca5] "=&s"(ca5), [ca6] "=&s"(ca6), [ca7] "=&s"(ca7), [cb0] "=&s"(cb0), [cb1] "=&s"(cb1),             \
-          [cb2] "=&s"(cb2), [cb3] "=&s"(cb3), [cb4] "=&s"(cb4), [cb5] "=&s"(cb5), [cb6] "=&s"(cb6),             \
-          [cb7] "=&s"(cb7)                                                                                      \
-        : [v] "v"(v)                                                                                            \
+          [d] "=&s"(d_), [lv] "=&s"(lv_), [nxt] "=&s"(nxt)                                                      \
+        : [ptr] "s"(tile_ptr), [p0] "s"(pk[0]), [p1] "s"(pk[1]), [p2] "s"(pk[2]), [p3] "s"(pk[3]),              \
+          [p4] "s"(pk[4]), [p5] "s"(pk[5]), [p6] "s"(pk[6]), [p7] "s"(pk[7]), [p8] "s"(pk[8]), [p9] "s"(pk[9]), \
+          [p10] "s"(pk[10]), [p11] "s"(pk[11]), [p12] "s"(pk[12]), [p13] "s"(pk[13]), [p14] "s"(pk[14]),        \
+          [p15] "s"(pk[15])                                                                                     \
         : "vcc", "scc", "s98", "s99")
 
 __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
@@ -328,38 +333,40 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     };
 
     uint32_t up = 0xFFFFFFFFu;                                         // ZLNG_MTF_TILE: t0 shifted down one lane
-    uint8_t* run = a.lit_byte + a.ctx_off[ctx];
+    uint8_t* run = a.lit_byte + a.ctx_off[ctx];                       // 64-byte aligned (k_ctx_offsets)
     const uint32_t n = a.ctx_total[ctx];
-    uint32_t vnext = lane < n ? (uint32_t)run[lane] : 0u;
+    typedef uint32_t Tile16 __attribute__((ext_vector_type(16)));
+    Tile16 pk;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pk) : "s"(run));     // first tile
     for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t v = vnext;
-        const uint32_t nidx = base + 64 + lane;
-        vnext = nidx < n ? (uint32_t)run[nidx] : 0u;                   // next tile in flight while this one is replayed
         uint32_t ranks = 0xFFFFFFFFu;
         if (base + 64 <= n) {
-            uint32_t ca0, ca1, ca2, ca3, ca4, ca5, ca6, ca7, cb0, cb1, cb2, cb3, cb4, cb5, cb6, cb7, i_, nx_, d_, lv_;
+            const uint8_t* tile_ptr = run + base;
+            Tile16 nxt;
+            uint32_t i_, nx_, d_, lv_;
             uint64_t m1_;
             ZLNG_MTF_TILE();
+            pk = nxt;
             const uint32_t rec = ranks;                                  // one-hot word, 0x80000000 | rank, 0 or the fill
             ranks = (rec & 0x80000000u) ? (rec & 0xFFu) : (uint32_t)__builtin_ctz(rec | 0x40000000u);
             if (__builtin_expect(lv_ != 0, 0)) {                         // a literal of rank >= 64 stopped the statement
 #define RANKSTORE(I, K) wrl(ranks, I, K)
+                const uint32_t v = run[base + lane];
                 const uint32_t kk = (uint32_t)__builtin_ctzll(__ballot(rec == 0u));
                 const uint32_t r = slow_step(rdl(v, kk));
                 wrl(ranks, r, kk);
                 for (uint32_t k = kk + 1; k < 64u; k++) ZLNG_MTF_STEP(k)
 #undef RANKSTORE
             }
+            run[base + lane] = (uint8_t)ranks;
         } else {
 #define RANKSTORE(I, K) wrl(ranks, I, K)
             const uint32_t cnt = n - base;
+            const uint32_t v = lane < cnt ? (uint32_t)run[base + lane] : 0u;
             for (uint32_t k = 0; k < cnt; k++) ZLNG_MTF_STEP(k)
 #undef RANKSTORE
+            if (lane < cnt) run[base + lane] = (uint8_t)ranks;
         }
-        // take delivery of the next tile BEFORE issuing the rank store: vmcnt retires in order, so a wait for
-        // the (long finished) load placed after the store would also wait for the store's round trip
-        asm volatile("" : "+v"(vnext));
-        if (base + lane < n) run[base + lane] = (uint8_t)ranks;
     }
     st[lane] = (uint8_t)t0; st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
 }

@@ -327,7 +327,7 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
             (rc = dev_alloc(c, &c->d_sub_off, nsubs)) || (rc = dev_alloc(c, &c->d_blk_end, nb)) ||
             (rc = dev_alloc(c, &c->d_summary, 8)) || (rc = dev_alloc(c, &c->d_tile_base, nb + 1)) ||
             (rc = dev_alloc(c, &c->d_tile_hist, nb * (kTokCap / 4096) * 256)) || (rc = dev_alloc(c, &c->d_ctx_total, 256)) ||
-            (rc = dev_alloc(c, &c->d_ctx_off, 256)) || (rc = dev_alloc(c, &c->d_lit_byte, nb * kTokCap)))
+            (rc = dev_alloc(c, &c->d_ctx_off, 256)) || (rc = dev_alloc(c, &c->d_lit_byte, nb * kTokCap + 256 * 64 + 128)))   // + run alignment + one tile of read-ahead
             return fail(rc);
         c->h_sched.resize(nsubs);
         c->h_nsub.resize(nb);
