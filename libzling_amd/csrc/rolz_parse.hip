@@ -501,7 +501,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
             const int P = __atomic_load_n(&pf_pos, __ATOMIC_RELAXED);
             if (__atomic_load_n(&pf_done, __ATOMIC_RELAXED)) break;
             int start = P + 64 > done_to ? P + 64 : done_to;
-            if (start >= P + 64 + 128 || start >= ilen) { __builtin_amdgcn_s_sleep(16); continue; }
+            if (start >= P + 64 + a.pf_ahead || start >= ilen) { __builtin_amdgcn_s_sleep(16); continue; }
             const LevelCfg pcfg = kAllL0 ? level_cfg(0) : level_cfg(__atomic_load_n(&pf_level, __ATOMIC_RELAXED));
             const int pos = start + lane;
             if (pos >= 4 && pos + kSentinel < ilen) {

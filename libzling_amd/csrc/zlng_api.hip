@@ -162,7 +162,8 @@ void launch_parse(zlng_ctx* c, const ParseArgs& pa, uint32_t nb) {
 // would have chosen differently.  At level 0 the schedule is always right (fallback == level).
 int run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, bool rank_now) {
     static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
-    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart};
+    static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
+    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead};
     launch_dict_reset(c->d_dict, nb, c->stream);
     timer_mark(c, "dict_reset");
     launch_parse(c, pa, nb);
