@@ -174,11 +174,13 @@ def main():
         tsrc = None
         kmap = {"rolz_parse": "k_rolz_parse_wave", "mtf_rank": "k_mtf_dense", "huff_pack": "k_pack"}
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            import glob
+            tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]      # newest committed pass
+            pj = json.load(open(tfile))
             wl = pj["workload"]
             if world == 1 and wl["bytes"] == args.size and wl["level"] == args.level and source == "synthetic":
                 traffic = pj["kernels"][kmap[dom]]["hbm_bytes_corrected"]
-                tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, (2*FETCH+WRITE)*1024)"
+                tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, (2*FETCH+WRITE)*1024)" % os.path.basename(tfile)
         except Exception:
             pass
         res = {
