@@ -97,6 +97,15 @@ int zlng_encode_blocks_device(zlng_ctx*, const void* d_in, size_t in_len,
 int zlng_encode_parse_device(zlng_ctx*, const void* d_in, size_t in_len);
 int zlng_encode_finish_device(zlng_ctx*, void* d_out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
 
+/* The same split with caller-owned host buffers, for a host-side pipeline over two contexts (the
+ * C++ shim): zlng_encode_parse copies `in` to the device and queues the parse on
+ * the context's own stream WITHOUT waiting for it; zlng_encode_finish imports nothing by itself
+ * (call zlng_set_state first when the range does not open the stream), runs rank + Huffman,
+ * copies the bytes back and returns when they are in `out`.  While one context finishes range k,
+ * another one can already parse range k+1. */
+int zlng_encode_parse(zlng_ctx*, const uint8_t* in, size_t in_len);
+int zlng_encode_finish(zlng_ctx*, uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+
 /* Stream state hand-off: 65,536 bytes of MTF tables (context-major) + current_level. */
 int zlng_get_state(zlng_ctx*, uint8_t mtf[ZLNG_MTF_STATE], int* current_level);
 int zlng_set_state(zlng_ctx*, const uint8_t mtf[ZLNG_MTF_STATE], int current_level);

@@ -424,6 +424,29 @@ int zlng_encode_finish_device(zlng_ctx* c, void* d_out, size_t out_cap, size_t* 
     return encode_device_impl(c, in, n, static_cast<uint8_t*>(d_out), out_cap, out_len, per_block_out_end, !reuse);
 }
 
+int zlng_encode_parse(zlng_ctx* c, const uint8_t* in, size_t in_len) {
+    if (!c || !c->is_encode || !in || in_len == 0) return ZLNG_E_ARG;
+    if (blocks_of(in_len) > c->max_blocks) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_in(c, in_len + 512)) || (rc = ensure_out(c, zlng_encode_bound(in_len)))) return rc;
+    CTX_HIP(hipMemcpyAsync(c->d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+    CTX_HIP(hipMemsetAsync(c->d_in + in_len, 0, 512, c->stream));
+    return zlng_encode_parse_device(c, c->d_in, in_len);
+}
+int zlng_encode_finish(zlng_ctx* c, uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end) {
+    if (!c || !c->pending_in || !out || !out_len) return ZLNG_E_ARG;
+    *out_len = 0;
+    size_t produced = 0;
+    const int rc = zlng_encode_finish_device(c, c->d_out, zlng_encode_bound(c->pending_len), &produced, per_block_out_end);
+    if (rc != ZLNG_OK) return rc;
+    if (produced > out_cap) return ZLNG_E_CAP;
+    CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    *out_len = produced;
+    return ZLNG_OK;
+}
+
 int zlng_get_state(zlng_ctx* c, uint8_t mtf[ZLNG_MTF_STATE], int* current_level) {
     if (!c || !mtf) return ZLNG_E_ARG;
     CTX_HIP(hipSetDevice(c->device));

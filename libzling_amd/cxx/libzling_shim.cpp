@@ -99,8 +99,49 @@ bool push_all(Outputter* out, unsigned char* p, size_t n) {       // src/libzlin
     return !out->IsErr();
 }
 
+// One batch of blocks on its way through the GPU.
+struct EncodeSlot {
+    zlng_ctx* ctx = nullptr;
+    std::vector<unsigned char> in, out;
+    std::vector<size_t> ilen, ends;
+    int have = 0;                 // blocks read into `in`
+    size_t total = 0;             // their bytes
+    bool in_flight = false;       // parse queued, finish not yet called
+    ~EncodeSlot() { if (ctx) zlng_destroy(ctx); }
+};
+
+void throw_rc(int rc) {
+    if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
+    if (rc != ZLNG_OK) throw std::runtime_error(std::string("baidu::zling::Encode(): ") + zlng_strerror(rc));
+}
+
+// fill up to nb blocks exactly as the reference fills one (src/libzling.cpp:193-196); false on an input error
+bool read_batch(Inputter* inputter, EncodeSlot& s, int nb) {
+    s.have = 0;
+    s.total = 0;
+    while (s.have < nb && !inputter->IsEnd() && !inputter->IsErr()) {
+        size_t got = 0;
+        unsigned char* dst = s.in.data() + (size_t)s.have * kBlock;
+        while (!inputter->IsEnd() && !inputter->IsErr() && got < kBlock) {
+            got += inputter->GetData(dst + got, kBlock - got);
+            if (inputter->IsErr()) break;
+        }
+        if (inputter->IsErr()) return false;
+        s.ilen[(size_t)s.have] = got;
+        s.total += got;
+        s.have++;
+        if (got < kBlock) break;              // a short block can only be the stream's last
+    }
+    return true;
+}
+
 }  // namespace
 
+// Schedule: two contexts take the batches alternately.  The parse of batch k+1 is queued on its
+// context's stream before batch k is finished, so on the GPU it runs beside batch k's rank + Huffman stages (the
+// parse does not depend on the MTF state, which travels context to context through 64 KiB of host memory), and the
+// caller's thread reads batch k+1 / writes batch k while kernels run.  Bytes and callbacks still leave block by
+// block, in stream order, on the caller's thread.  ZLNG_PIPELINE=0 keeps everything on one context.
 int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int level) {
     if (handler) {
         handler->SetInputterOutputter(inputter, outputter, true);
@@ -109,38 +150,52 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
     bool bad_level = level < 0 || level > 4;     // the reference would emit a corrupt stream
     if (!bad_level) {
         const int nb = batch_blocks();
-        CtxGuard ctx(make_ctx(level, true, nb));
-        std::vector<unsigned char> in((size_t)nb * kBlock), out(zlng_encode_bound((size_t)nb * kBlock));
-        std::vector<size_t> ilen((size_t)nb), ends((size_t)nb);
-        bool failed = false;
-        while (!failed && !inputter->IsEnd() && !inputter->IsErr()) {
-            // fill up to nb blocks exactly as the reference fills one (src/libzling.cpp:193-196)
-            int have = 0;
-            size_t total = 0;
-            while (have < nb && !inputter->IsEnd() && !inputter->IsErr()) {
-                size_t got = 0;
-                unsigned char* dst = in.data() + (size_t)have * kBlock;
-                while (!inputter->IsEnd() && !inputter->IsErr() && got < kBlock) {
-                    got += inputter->GetData(dst + got, kBlock - got);
-                    if (inputter->IsErr()) break;
-                }
-                if (inputter->IsErr()) { failed = true; break; }
-                ilen[(size_t)have] = got;
-                total += got;
-                have++;
-                if (got < kBlock) break;          // a short block can only be the stream's last
-            }
-            if (failed || have == 0) break;
+        const char* pe = getenv("ZLNG_PIPELINE");
+        const int nslots = (pe && atoi(pe) == 0) ? 1 : 2;
+        EncodeSlot slot[2];
+        auto prepare = [&](EncodeSlot& s) {      // the second context is only created when a second batch exists
+            if (s.ctx) return;
+            s.ctx = make_ctx(level, true, nb);
+            s.in.resize((size_t)nb * kBlock);
+            s.out.resize(zlng_encode_bound((size_t)nb * kBlock));
+            s.ilen.resize((size_t)nb);
+            s.ends.resize((size_t)nb);
+        };
+        std::vector<unsigned char> state(ZLNG_MTF_STATE);
+        int state_level = level;
+        bool have_state = false, failed = false;
+        // finish the batch in `s`: import the stream state left by the previous batch, run the back half, emit
+        auto finish = [&](EncodeSlot& s) {
+            if (have_state) throw_rc(zlng_set_state(s.ctx, state.data(), state_level));
             size_t produced = 0;
-            int rc = zlng_encode_blocks(ctx.c, in.data(), total, out.data(), out.size(), &produced, ends.data());
-            if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
-            if (rc != ZLNG_OK) throw std::runtime_error(std::string("baidu::zling::Encode(): ") + zlng_strerror(rc));
+            throw_rc(zlng_encode_finish(s.ctx, s.out.data(), s.out.size(), &produced, s.ends.data()));
+            s.in_flight = false;
+            throw_rc(zlng_get_state(s.ctx, state.data(), &state_level));
+            have_state = true;
             size_t prev = 0;
-            for (int b = 0; b < have; b++) {      // bytes, then the callback, block by block
-                if (!push_all(outputter, out.data() + prev, ends[(size_t)b] - prev)) { failed = true; break; }
-                prev = ends[(size_t)b];
-                if (handler) handler->OnProcess(in.data() + (size_t)b * kBlock, ilen[(size_t)b]);
+            for (int b = 0; b < s.have; b++) {   // bytes, then the callback, block by block (src/libzling.cpp:273-283)
+                if (!push_all(outputter, s.out.data() + prev, s.ends[(size_t)b] - prev)) { failed = true; return; }
+                prev = s.ends[(size_t)b];
+                if (handler) handler->OnProcess(s.in.data() + (size_t)b * kBlock, s.ilen[(size_t)b]);
             }
+        };
+        int k = 0;
+        while (!failed && !inputter->IsEnd() && !inputter->IsErr()) {
+            EncodeSlot& cur = slot[k % nslots];
+            EncodeSlot& prv = slot[(k + nslots - 1) % nslots];
+            if (cur.in_flight) finish(cur);      // one context only: nothing overlaps
+            if (failed) break;
+            prepare(cur);
+            if (!read_batch(inputter, cur, nb)) { failed = true; break; }
+            if (cur.have == 0) break;
+            throw_rc(zlng_encode_parse(cur.ctx, cur.in.data(), cur.total));
+            cur.in_flight = true;
+            if (nslots == 2 && prv.in_flight) finish(prv);
+            k++;
+        }
+        for (int i = 0; i < nslots && !failed; i++) {      // drain, oldest first
+            EncodeSlot& s = slot[(k + i) % nslots];
+            if (s.in_flight && !inputter->IsErr()) finish(s);
         }
     }
     if (handler) handler->OnDone();

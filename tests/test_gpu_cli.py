@@ -70,3 +70,51 @@ def test_python_stream_called_block_by_block(oracle):
         for off in range(0, x.size, zl.BLOCK):
             parts.append(s.encode(x[off:off + zl.BLOCK]))
     assert np.array_equal(np.concatenate(parts), want)
+
+
+@pytest.mark.parametrize("level,batch,pipeline", [(0, 1, "1"), (0, 2, "1"), (4, 1, "1"), (2, 2, "1"), (4, 1, "0")])
+def test_shim_pipeline_over_two_contexts(oracle, level, batch, pipeline):
+    """batches alternate between two contexts, the parse of batch k+1 is queued before batch k is
+    finished and the MTF tables + current_level travel between the contexts through host memory.  Five blocks with a
+    random (incompressible) stretch in the middle, so at e2/e4 the level adaptation (src/libzling.cpp:261-266) flips
+    across a batch boundary: the finishing context must notice that its parse was speculated at the wrong entry level."""
+    import libzling_amd as zl
+    from oracle_py import textgen
+    rng = np.random.default_rng(77)
+    x = np.concatenate([textgen(zl.BLOCK + 300_000, 5), rng.integers(0, 256, zl.BLOCK, dtype=np.uint8),
+                        textgen(2 * zl.BLOCK + 123_457, 6)])
+    want = oracle.encode(x, level)
+    env = dict(os.environ, ZLNG_BATCH_BLOCKS=str(batch), ZLNG_PIPELINE=pipeline)
+    p = subprocess.run([DEMO, "e%d" % level], input=x.tobytes(), stdout=subprocess.PIPE, check=True, env=env)
+    assert np.array_equal(np.frombuffer(p.stdout, dtype=np.uint8), want)
+
+
+def test_split_host_api_matches_one_call(oracle):
+    """zlng_encode_parse / zlng_encode_finish (host buffers) on two contexts by hand == one zlng_encode_blocks call."""
+    import ctypes as C
+    import libzling_amd as zl
+    from oracle_py import textgen
+    L = zl.lib()
+    L.zlng_encode_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zlng_encode_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    x = textgen(3 * zl.BLOCK + 1000, 12)
+    want = oracle.encode(x, 0)
+    cuts = [0, 2 * zl.BLOCK, x.size]
+    with zl.Stream(0, 0, True, 2) as a, zl.Stream(0, 0, True, 2) as b:
+        parts = []
+        ctxs = [a, b]
+        for i in range(2):                       # both parses are queued before anything is finished
+            seg = np.ascontiguousarray(x[cuts[i]:cuts[i + 1]])
+            assert L.zlng_encode_parse(ctxs[i]._h, seg.ctypes.data, seg.size) == 0
+            ctxs[i]._seg = seg
+        st = None
+        for i in range(2):
+            if st is not None:
+                ctxs[i].set_state(*st)
+            out = np.empty(zl.encode_bound(ctxs[i]._seg.size), dtype=np.uint8)
+            n = C.c_size_t(0)
+            ends = (C.c_size_t * 2)()
+            assert L.zlng_encode_finish(ctxs[i]._h, out.ctypes.data, out.size, C.byref(n), ends) == 0
+            parts.append(out[:n.value].copy())
+            st = ctxs[i].get_state()
+    assert np.array_equal(np.concatenate(parts), want)
