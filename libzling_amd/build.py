@@ -40,7 +40,7 @@ def build_hip(force=False, verbose=False):
         o = s[:-4] + ".o"
         if force or _stale(o, deps):
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-                   "-Wall", "-Wno-unused-function", "-c", s, "-o", o]
+                   "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

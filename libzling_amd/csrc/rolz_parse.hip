@@ -817,7 +817,7 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
                             }
                             if (spec_match) word = (258u + spec_len - kMatchMin) | ((head - mnode) & (kRing - 1)) << 16;
                             else word = b_0 | ctx << 16;
-                            tok[nt + (uint32_t)__popcll(com & below)] = word;
+                            __builtin_nontemporal_store(word, &tok[nt + (uint32_t)__popcll(com & below)]);   // streamed out: keep L2 for the dictionary
                         }
                         const int lastl = top_bit(com);
                         const bool last_match = ((match_lanes >> lastl) & 1ull) != 0;
