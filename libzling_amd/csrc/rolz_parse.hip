@@ -463,7 +463,7 @@ __device__ __forceinline__ void wsync() {
 // change): the generic speculation and the level tests drop out of the kernel.
 // kProf: cycle counters into a.dbg (ZLNG_PROFILE=1); compiled out of the production kernels.
 template <bool kAllL0, bool kProf>
-__global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
+__global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     __shared__ uint16_t heads[256];
     __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
     __shared__ unsigned long long keytab[kKeyTab];
@@ -492,7 +492,10 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
     }
     __syncthreads();                                 // the only workgroup barrier: wave 1 never joins another one
 
-    if (wave == 1) {
+    if (wave >= 1) {
+        // wave 1 runs furthest ahead (span pf_ahead), every further wave re-touches a nearer 64-position window
+        const int nw = a.pf_waves;
+        const int near_lead = 64 * (nw - wave), span = wave == 1 ? a.pf_ahead : 64;
         // ---- prefetch wavefront: runs the same speculative loads for the next window(s), results discarded.
         // It only warms L2/L1 for the dependent chain (hash head -> ring entry -> source bytes) that bounds
         // phase 1; correctness never depends on it (no LDS/global writes, benign race on pf_pos).
@@ -500,8 +503,8 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
         while (true) {
             const int P = __atomic_load_n(&pf_pos, __ATOMIC_RELAXED);
             if (__atomic_load_n(&pf_done, __ATOMIC_RELAXED)) break;
-            int start = P + 64 > done_to ? P + 64 : done_to;
-            if (start >= P + 64 + a.pf_ahead || start >= ilen) { __builtin_amdgcn_s_sleep(16); continue; }
+            int start = P + 64 + near_lead > done_to ? P + 64 + near_lead : done_to;
+            if (start >= P + 64 + near_lead + span || start >= ilen) { __builtin_amdgcn_s_sleep(16); continue; }
             const LevelCfg pcfg = kAllL0 ? level_cfg(0) : level_cfg(__atomic_load_n(&pf_level, __ATOMIC_RELAXED));
             const int pos = start + lane;
             if (pos >= 4 && pos + kSentinel < ilen) {
@@ -872,10 +875,10 @@ __global__ __launch_bounds__(128) void k_rolz_parse_wave(ParseArgs a) {
 
 void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0) {
     const bool prof = a.dbg != nullptr;
-    if (all_level0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wave<true, false>), dim3(nblocks), dim3(128), 0, s, a);
-    else if (all_level0) hipLaunchKernelGGL((k_rolz_parse_wave<true, true>), dim3(nblocks), dim3(128), 0, s, a);
-    else if (!prof) hipLaunchKernelGGL((k_rolz_parse_wave<false, false>), dim3(nblocks), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((k_rolz_parse_wave<false, true>), dim3(nblocks), dim3(128), 0, s, a);
+    if (all_level0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wave<true, false>), dim3(nblocks), dim3(64 * (1 + a.pf_waves)), 0, s, a);
+    else if (all_level0) hipLaunchKernelGGL((k_rolz_parse_wave<true, true>), dim3(nblocks), dim3(64 * (1 + a.pf_waves)), 0, s, a);
+    else if (!prof) hipLaunchKernelGGL((k_rolz_parse_wave<false, false>), dim3(nblocks), dim3(64 * (1 + a.pf_waves)), 0, s, a);
+    else hipLaunchKernelGGL((k_rolz_parse_wave<false, true>), dim3(nblocks), dim3(64 * (1 + a.pf_waves)), 0, s, a);
 }
 
 }  // namespace zlng

@@ -163,7 +163,8 @@ void launch_parse(zlng_ctx* c, const ParseArgs& pa, uint32_t nb) {
 int run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, bool rank_now) {
     static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
     static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
-    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead};
+    static const int pf_waves = getenv("ZLNG_PF_WAVES") ? std::min(3, std::max(1, atoi(getenv("ZLNG_PF_WAVES")))) : 1;
+    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves};
     launch_dict_reset(c->d_dict, nb, c->stream);
     timer_mark(c, "dict_reset");
     launch_parse(c, pa, nb);

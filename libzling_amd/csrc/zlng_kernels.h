@@ -16,7 +16,8 @@ struct ParseArgs {
     const uint8_t* lvl_sched; // NB x kMaxSub: level of each sub-block (src/libzling.cpp:261-266 speculation)
     unsigned long long* dbg;  // optional NB x 16 counters (cycles per phase, rounds, redos); may be null
     int            min_restart; // a conflict at lane >= this restarts the round there instead of replaying the token
-    int            pf_ahead;    // how many positions past the next window the prefetch wavefront may run (tuning)
+    int            pf_ahead;    // how many positions past its lead the far prefetch wavefront may run (tuning)
+    int            pf_waves;    // prefetch wavefronts per block (1..3)
 };
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s);
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
