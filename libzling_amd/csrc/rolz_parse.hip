@@ -466,10 +466,12 @@ template <bool kAllL0, bool kProf>
 __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     __shared__ uint16_t heads[256];
     __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
-    __shared__ unsigned long long keytab[kKeyTab];
-    __shared__ unsigned long long ctxtab[256];
-    __shared__ unsigned long long evtab[kEvTab];
-    __shared__ unsigned long long ektab[256];
+    // lane-mask tables; the extra last entry of each is a sink: lanes past the end of the block (not live / no room
+    // for a match) deposit and clear there, so none of these accesses sits under an exec-mask branch
+    __shared__ unsigned long long keytab[kKeyTab + 1];
+    __shared__ unsigned long long ctxtab[256 + 1];
+    __shared__ unsigned long long evtab[kEvTab + 1];
+    __shared__ unsigned long long ektab[256 + 1];
     __shared__ unsigned long long pred_mask;         // lanes that are the in-slot predecessor of a later lane of the same commit set
     __shared__ int pf_pos, pf_level, pf_done;        // round start / level / end flag published for the prefetch wave
     const uint32_t blk = blockIdx.x;
@@ -486,8 +488,8 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     const unsigned long long below = lane_bit - 1ull, beloweq = below | lane_bit;
 
     if (wave == 0) {
-        for (int i = lane; i < 256; i += 64) { heads[i] = 0; ctxtab[i] = 0; ektab[i] = 0; }
-        for (int i = lane; i < kKeyTab; i += 64) { keytab[i] = 0; evtab[i] = 0; }
+        for (int i = lane; i < 256 + 1; i += 64) { if (i < 256) heads[i] = 0; ctxtab[i] = 0; ektab[i] = 0; }
+        for (int i = lane; i < kKeyTab + 1; i += 64) { keytab[i] = 0; evtab[i] = 0; }
         if (lane == 0) { pf_pos = 0; pf_level = a.lvl_sched[blk * kMaxSub]; pf_done = 0; }
     }
     __syncthreads();                                 // the only workgroup barrier: wave 1 never joins another one
@@ -570,15 +572,17 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             const uint32_t cw = b_0 << 8 | b_1;                    // check: mru[ctx] vs (b0, b1)
             const uint32_t ek = b_m3, ew = b_m2 << 8 | ctx;        // event at this boundary: mru[b-3] <- (b-2, b-1)
             const uint32_t evix = ev_ix(ek, ew), chix = ev_ix(ctx, cw);
-            if (live) { atomicOr(&evtab[evix], lane_bit); atomicOr(&ektab[ek], lane_bit); }
+            const uint32_t evix_w = live ? evix : (uint32_t)kEvTab, ek_w = live ? ek : 256u;
+            atomicOr(&evtab[evix_w], lane_bit); atomicOr(&ektab[ek_w], lane_bit);
 
             Spec S;
             S.sp = kMatchMin - 1; S.node0 = 65535; S.head0 = 0; S.dmin = kRing - 1;
             S.lkix1 = S.lkix2 = S.lctx1 = S.lctx2 = 0; S.lz1 = S.lz2 = false;
             S.len0 = 0; S.lsrc1 = 0; S.qa = Quad{0, 0, 0, 0};
+            const uint32_t kix_w = canm ? kix : (uint32_t)kKeyTab, ctx_w = canm ? ctx : 256u;
+            atomicOr(&keytab[kix_w], lane_bit);
+            atomicOr(&ctxtab[ctx_w], lane_bit);
             if (canm) {
-                atomicOr(&keytab[kix], lane_bit);
-                atomicOr(&ctxtab[ctx], lane_bit);
                 if (level0) speculate_l0(S, dict, buf, heads, pos, qtext, ctx, hc, chk);
                 else speculate(S, dict, buf, heads, pos, cfg, qtext, ctx, hc, chk);
             }
@@ -587,19 +591,24 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             const bool lz1 = S.lz1, lz2 = S.lz2;
             if (prof) t1 = __builtin_readcyclecounter();
             wsync();                         // all lane bits are in the tables
-            unsigned long long keymask = 0, ctxmask = 0, lkey = 0;
-            if (canm) { keymask = keytab[kix]; ctxmask = ctxtab[ctx]; }
+            unsigned long long lkey = 0;
+            const unsigned long long keymask_r = keytab[kix_w], ctxmask_r = ctxtab[ctx_w];
+            const unsigned long long keymask = canm ? keymask_r : 0ull, ctxmask = canm ? ctxmask_r : 0ull;
             // a lazy probe is invalidated by an accepted insert with its key, or -- if it walked near the
             // ring head -- by any accepted insert into its bucket
             // (at level 0 the probe's read set is kept for every lane: the in-register conflict fix can change a length
             //  and then needs a probe the speculation did not evaluate)
-            if (lz1 || (level0 && canm)) lkey |= keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
+            if (level0) {                            // (lkix1 / lctx1 are 0 for lanes without a speculation: harmless reads)
+                const unsigned long long lk = keytab[lkix1], lc = ctxtab[lctx1];
+                lkey = canm ? (lk | ((sp & kSpRisk1) ? lc : 0ull)) : 0ull;
+            } else if (lz1) lkey |= keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
             if (lz2) lkey |= keytab[lkix2] | ((sp & kSpRisk2) ? ctxtab[lctx2] : 0ull);
-            const unsigned long long hitmask = live ? evtab[chix] : 0ull;   // boundaries whose (key, word) may equal my check
-            const unsigned long long samekey = live ? ektab[ek] : 0ull;     // boundaries with my event key
+            const unsigned long long hit_r = evtab[chix], same_r = ektab[ek_w];
+            const unsigned long long hitmask = live ? hit_r : 0ull;         // boundaries whose (key, word) may equal my check
+            const unsigned long long samekey = live ? same_r : 0ull;        // boundaries with my event key
             wsync();
-            if (canm) { keytab[kix] = 0; ctxtab[ctx] = 0; }
-            if (live) { evtab[evix] = 0; ektab[ek] = 0; }
+            keytab[kix_w] = 0; ctxtab[ctx_w] = 0;
+            evtab[evix_w] = 0; ektab[ek_w] = 0;
 
             // speculative token of this lane: match (if not vetoed by its speculative lazy probes) or literal
             const uint32_t spec_len = sp & kSpLenMask;
