@@ -590,6 +590,38 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             const uint32_t lkix1 = S.lkix1, lkix2 = S.lkix2, lctx1 = S.lctx1, lctx2 = S.lctx2;
             const bool lz1 = S.lz1, lz2 = S.lz2;
             if (prof) t1 = __builtin_readcyclecounter();
+            // speculative token of this lane: match (if not vetoed by its speculative lazy probes) or literal
+            const uint32_t spec_len = sp & kSpLenMask;
+            const bool spec_veto = ((sp & kSpVeto1) != 0) || (cfg.lazy2 > 0 && (sp & kSpVeto2) != 0);
+            const bool spec_match = canm && spec_len >= (uint32_t)kMatchMin && !(spec_len < (uint32_t)kLazyLimit && spec_veto);
+            const uint32_t tlen = spec_match ? spec_len : 1u;
+            const unsigned long long match_lanes = __ballot(spec_match);
+            // eight-token jumps for the chase: next start after 8 tokens and the starts passed on the way (three
+            // doubling steps over ds_bpermute; a lone wave pays ~100 cycles per scalar hop otherwise).  The first
+            // step's mask is known without a shuffle: the token after mine starts at lane n1, if that lane is live.
+            uint32_t hop_next;
+            unsigned long long hop_mask;
+            {
+                auto shfl64 = [](unsigned long long v, uint32_t src) {
+                    return (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src) << 32 | (uint32_t)__shfl((int)(uint32_t)v, (int)src);
+                };
+                const uint32_t n1 = live ? min((uint32_t)lane + tlen, 64u) : 64u;
+                const bool v1 = n1 < 64u && P + (int)n1 < ilen;
+                const uint32_t n2g = (uint32_t)__shfl((int)n1, (int)(n1 & 63u));
+                const uint32_t n2 = v1 ? n2g : 64u;
+                const unsigned long long m2 = (live ? lane_bit : 0ull) | (v1 ? 1ull << (n1 & 63u) : 0ull);
+                const bool v2 = n2 < 64u;
+                const uint32_t n4g = (uint32_t)__shfl((int)n2, (int)(n2 & 63u));
+                const unsigned long long m2g = shfl64(m2, n2 & 63u);
+                const uint32_t n4 = v2 ? n4g : 64u;
+                const unsigned long long m4 = m2 | (v2 ? m2g : 0ull);
+                const bool v4 = n4 < 64u;
+                const uint32_t n8g = (uint32_t)__shfl((int)n4, (int)(n4 & 63u));
+                const unsigned long long m4g = shfl64(m4, n4 & 63u);
+                hop_next = v4 ? n8g : 64u;
+                hop_mask = m4 | (v4 ? m4g : 0ull);
+            }
+
             wsync();                         // all lane bits are in the tables
             unsigned long long lkey = 0;
             const unsigned long long keymask_r = keytab[kix_w], ctxmask_r = ctxtab[ctx_w];
@@ -609,33 +641,6 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             wsync();
             keytab[kix_w] = 0; ctxtab[ctx_w] = 0;
             evtab[evix_w] = 0; ektab[ek_w] = 0;
-
-            // speculative token of this lane: match (if not vetoed by its speculative lazy probes) or literal
-            const uint32_t spec_len = sp & kSpLenMask;
-            const bool spec_veto = ((sp & kSpVeto1) != 0) || (cfg.lazy2 > 0 && (sp & kSpVeto2) != 0);
-            const bool spec_match = canm && spec_len >= (uint32_t)kMatchMin && !(spec_len < (uint32_t)kLazyLimit && spec_veto);
-            const uint32_t tlen = spec_match ? spec_len : 1u;
-            const unsigned long long match_lanes = __ballot(spec_match);
-            // four-token jumps for the chase: next start after 4 tokens and the starts passed on the way
-            // (two doubling steps over ds_bpermute; a lone wave pays ~100 cycles per scalar hop otherwise)
-            uint32_t hop_next;
-            unsigned long long hop_mask;
-            {
-                const uint32_t n1 = live ? min((uint32_t)lane + tlen, 64u) : 64u;
-                const unsigned long long m1 = live ? lane_bit : 0ull;
-                const bool v1 = n1 < 64u;
-                const uint32_t n2g = (uint32_t)__shfl((int)n1, (int)(n1 & 63u));
-                const unsigned long long m1g = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(m1 >> 32), (int)(n1 & 63u)) << 32 |
-                                               (uint32_t)__shfl((int)(uint32_t)m1, (int)(n1 & 63u));
-                const uint32_t n2 = v1 ? n2g : 64u;
-                const unsigned long long m2 = m1 | (v1 ? m1g : 0ull);
-                const bool v2 = n2 < 64u;
-                const uint32_t n4g = (uint32_t)__shfl((int)n2, (int)(n2 & 63u));
-                const unsigned long long m2g = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(m2 >> 32), (int)(n2 & 63u)) << 32 |
-                                               (uint32_t)__shfl((int)(uint32_t)m2, (int)(n2 & 63u));
-                hop_next = v2 ? n4g : 64u;
-                hop_mask = m2 | (v2 ? m2g : 0ull);
-            }
 
             // ---------------- phase 2
             if (prof) { t2 = __builtin_readcyclecounter(); c_p1 += t1 - t0; c_mask += t2 - t1; n_round++; }
