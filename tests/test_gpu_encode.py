@@ -128,3 +128,24 @@ def test_rejects_bad_arguments(zl):
         with pytest.raises(zl.ZlngError):
             s.encode(np.zeros(2 * zl.BLOCK, np.uint8))      # more blocks than the context was sized for
         assert s.encode(np.zeros(0, np.uint8)).size == 0    # empty input -> empty stream
+
+
+def test_split_host_api_rejects_misuse(zl):
+    """zlng_encode_finish without a pending parse, a parse on a decode context and oversized ranges fail with
+    ZLNG_E_ARG instead of touching memory."""
+    import ctypes as C
+    L = zl.lib()
+    L.zlng_encode_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zlng_encode_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    x = np.zeros(1000, np.uint8)
+    out = np.empty(zl.encode_bound(x.size), np.uint8)
+    n = C.c_size_t(0)
+    with zl.Stream(0, 0, True, 1) as s:
+        assert L.zlng_encode_finish(s._h, out.ctypes.data, out.size, C.byref(n), None) == -1          # nothing parsed
+        assert L.zlng_encode_parse(s._h, x.ctypes.data, 0) == -1
+        big = np.zeros(2 * zl.BLOCK, np.uint8)
+        assert L.zlng_encode_parse(s._h, big.ctypes.data, big.size) == -1                             # > max_blocks
+        assert L.zlng_encode_parse(s._h, x.ctypes.data, x.size) == 0
+        assert L.zlng_encode_finish(s._h, out.ctypes.data, 4, C.byref(n), None) == -3                 # ZLNG_E_CAP
+    with zl.Stream(0, 0, False, 1) as d:
+        assert L.zlng_encode_parse(d._h, x.ctypes.data, x.size) == -1                                 # decode context
