@@ -244,27 +244,27 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
 //     (next <= rank - 2 from rank 21 on, so t0[next] is untouched); mtfnext = (rank * 62263) >> 16 below 128.
 //     The rank is recorded as 0x80000000 | rank.
 //   rank >= 64 (c not in t0, nothing was changed): leave the statement with lv = 1; lane K of ranks holds 0.
-// v_readlane / v_writelane lane selects come from SALU results or M0 (no wait states owed).  SCC is set again
-// before re-entering step KN, whose late branch is evaluated a second time.
+// v_readlane / v_writelane lane selects come from SALU results or M0 (no wait states owed); both reads of t0
+// happen before its first write (next <= rank - 2, so the three lanes are distinct).  VCC is free here: step KN
+// recomputes it.  SCC is set again before re-entering step KN, whose late branch is evaluated a second time.
 #define ZLNG_MTF_G_SLOW(PK, B, K, KN)                                                                           \
     "1" #K ":\n\t"                                                                                              \
-    "v_cmp_eq_u32_sdwa s[98:99], %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                     \
-    "s_cmp_eq_u64 s[98:99], 0\n\t"                                                                              \
-    "s_cbranch_scc1 8f\n\t"                                                                                     \
-    "s_ff1_i32_b64 %[nx], s[98:99]\n\t"                                                                         \
-    "s_add_u32 %[i], %[nx], 1\n\t"                                                                              \
-    "v_readlane_b32 %[d], %[t0], %[i]\n\t"                                                                      \
-    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
-    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
-    "s_mul_i32 %[nx], %[i], 0xf337\n\t"                                                                         \
-    "s_lshr_b32 %[nx], %[nx], 16\n\t"                                                                           \
-    "v_readlane_b32 %[d], %[t0], %[nx]\n\t"                                                                     \
-    "s_mov_b32 m0, %[i]\n\t"                                                                                    \
-    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
-    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "v_cmp_eq_u32_sdwa vcc, %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
     "s_bfe_u32 %[d], %[" #PK "], (8 * " #B ") | (8 << 16)\n\t"                                                  \
+    "s_cbranch_vccz 8f\n\t"                                                                                     \
+    "s_ff1_i32_b64 %[nx], vcc\n\t"                                                                              \
+    "s_add_u32 %[i], %[nx], 1\n\t"                                                                              \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "s_mul_i32 %[nx], %[i], 0xf337\n\t"                                                                         \
+    "v_readlane_b32 %[da], %[t0], %[i]\n\t"                                                                     \
+    "s_lshr_b32 %[nx], %[nx], 16\n\t"                                                                           \
+    "v_readlane_b32 %[db], %[t0], %[nx]\n\t"                                                                    \
+    "v_writelane_b32 %[t0], %[da], m0\n\t"                                                                      \
+    "s_mov_b32 m0, %[i]\n\t"                                                                                    \
+    "v_writelane_b32 %[t0], %[db], m0\n\t"                                                                      \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
     "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
-    "s_or_b32 %[i], %[i], 0x80000000\n\t"                                                                       \
+    "s_bitset1_b32 %[i], 31\n\t"                                                                                \
     "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
     "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
     "s_branch 2" #KN "b\n\t"
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
         "9:\n\t"                                                                                                \
         "s_waitcnt lgkmcnt(0)"                                                                                  \
         : [t0] "+v"(t0), [up] "+v"(up), [ranks] "+v"(ranks), [m1] "=&s"(m1_), [i] "=&s"(i_), [nx] "=&s"(nx_),   \
-          [d] "=&s"(d_), [lv] "=&s"(lv_), [nxt] "=&s"(nxt)                                                      \
+          [d] "=&s"(d_), [da] "=&s"(da_), [db] "=&s"(db_), [lv] "=&s"(lv_), [nxt] "=&s"(nxt)                    \
         : [ptr] "s"(tile_ptr), [p0] "s"(pk[0]), [p1] "s"(pk[1]), [p2] "s"(pk[2]), [p3] "s"(pk[3]),              \
           [p4] "s"(pk[4]), [p5] "s"(pk[5]), [p6] "s"(pk[6]), [p7] "s"(pk[7]), [p8] "s"(pk[8]), [p9] "s"(pk[9]), \
           [p10] "s"(pk[10]), [p11] "s"(pk[11]), [p12] "s"(pk[12]), [p13] "s"(pk[13]), [p14] "s"(pk[14]),        \
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
         if (base + 64 <= n) {
             const uint8_t* tile_ptr = run + base;
             Tile16 nxt;
-            uint32_t i_, nx_, d_, lv_;
+            uint32_t i_, nx_, d_, da_, db_, lv_;
             uint64_t m1_;
             ZLNG_MTF_TILE();
             pk = nxt;
