@@ -322,7 +322,9 @@ __device__ __forceinline__ uint32_t lcp_tail(const uint8_t* a, const uint8_t* b,
 // wave-uniformly (`while any lane is still walking`) with per-lane predicates instead of per-lane breaks: a divergent
 // break costs a handful of exec-mask instructions per lane group, a uniform loop costs one scalar branch.
 __device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, int ppos, uint32_t lctx, uint32_t first, uint32_t lov,
-                                            uint32_t m, int depth, uint32_t lhead, bool active, bool& veto, uint32_t& ld) {
+                                            uint32_t lsfx, uint32_t m, int depth, uint32_t lhead, bool active, bool& veto, uint32_t& ld) {
+    // (n, lov = offset[n], lsfx = suffix[n]) travel together, so a chain hop is ONE round trip: the source word
+    // of node n and both ring fields of its successor are requested at the same time
     Bucket B(dict, lctx);
     uint32_t n = first;
     active = active && n != 65535u;
@@ -331,13 +333,14 @@ __device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, i
         if (active) ld = min(ld, ring_dist(n, lhead));
         const uint32_t off = lov & 0xFFFFFF;
         const uint32_t srcw = ld32u(buf + (active ? off + m : (uint32_t)ppos));
-        const uint32_t nn = B.suffix[n & (kRing - 1)];
+        const uint32_t nn = lsfx;
+        const uint32_t nov = B.offset[nn & (kRing - 1)];
+        const uint32_t nsfx = B.suffix[nn & (kRing - 1)];
         if (active && probe == srcw) { veto = true; active = false; }
         active = active && nn != 65535u;
         if (active) ld = min(ld, ring_dist(nn, lhead));
-        const uint32_t nov = B.offset[nn & (kRing - 1)];
         active = active && !(off <= (nov & 0xFFFFFF));
-        n = nn; lov = nov;
+        n = nn; lov = nov; lsfx = nsfx;
     }
 }
 
@@ -357,6 +360,7 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     uint32_t ov = B.offset[node0 & (kRing - 1)];
     uint32_t nx = B.suffix[node0 & (kRing - 1)];
     const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
+    const uint32_t lsf1 = B1.suffix[ln1 & (kRing - 1)], lsf2 = B2.suffix[ln2 & (kRing - 1)];
 
     uint32_t maxlen = kMatchMin - 1, maxnode = 0, node = node0, dmin = kRing - 1;
     bool active = node0 != 65535u;
@@ -381,8 +385,8 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     const uint32_t m = lz ? maxlen - 3u : 0u;
     bool v1 = false, v2 = false;
     uint32_t ld1 = kRing - 1, ld2 = kRing - 1;
-    if (want1) lazy_spec_u(dict, buf, pos + 1, lctx1, ln1, lov1, m, cfg.lazy1, lhead1, lz, v1, ld1);
-    if (want2) lazy_spec_u(dict, buf, pos + 2, lctx2, ln2, lov2, m, cfg.lazy2, lhead2, lz, v2, ld2);
+    if (want1) lazy_spec_u(dict, buf, pos + 1, lctx1, ln1, lov1, lsf1, m, cfg.lazy1, lhead1, lz, v1, ld1);
+    if (want2) lazy_spec_u(dict, buf, pos + 2, lctx2, ln2, lov2, lsf2, m, cfg.lazy2, lhead2, lz, v2, ld2);
     if (v1) sp |= kSpVeto1;
     if (v2) sp |= kSpVeto2;
     if (ld1 < kRiskDist) sp |= kSpRisk1;
