@@ -62,7 +62,7 @@ def build_shim(force=False):
         return None
     deps = srcs + glob.glob(os.path.join(ROOT, "include", "libzling", "*.h")) + [os.path.join(ROOT, "include", "zlng.h")]
     if force or _stale(SHIM_SO, deps) or _stale(SHIM_SO, [HIP_SO]):
-        subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"),
                                "-I", os.path.join(ROOT, "include", "libzling"), "-o", SHIM_SO] + srcs +
                               ["-L", PKG, "-lzlng_hip", "-Wl,-rpath,$ORIGIN", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     return SHIM_SO

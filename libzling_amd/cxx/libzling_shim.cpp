@@ -9,6 +9,7 @@
 // blocks are parsed concurrently; per_block_out_end lets the bytes and callbacks still be emitted
 // block by block in stream order.
 #include <algorithm>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -106,7 +107,6 @@ struct EncodeSlot {
     std::vector<size_t> ilen, ends;
     int have = 0;                 // blocks read into `in`
     size_t total = 0;             // their bytes
-    bool in_flight = false;       // parse queued, finish not yet called
     ~EncodeSlot() { if (ctx) zlng_destroy(ctx); }
 };
 
@@ -137,11 +137,12 @@ bool read_batch(Inputter* inputter, EncodeSlot& s, int nb) {
 
 }  // namespace
 
-// Schedule: two contexts take the batches alternately.  The parse of batch k+1 is queued on its
-// context's stream before batch k is finished, so on the GPU it runs beside batch k's rank + Huffman stages (the
-// parse does not depend on the MTF state, which travels context to context through 64 KiB of host memory), and the
-// caller's thread reads batch k+1 / writes batch k while kernels run.  Bytes and callbacks still leave block by
-// block, in stream order, on the caller's thread.  ZLNG_PIPELINE=0 keeps everything on one context.
+// Schedule: two contexts take the batches alternately.  For batch k the caller's thread reads the
+// blocks and queues the parse (zlng_encode_parse returns once the copy is staged), then a helper thread runs the
+// blocking GPU half -- import the 64 KiB stream state left by batch k-1, rank + Huffman + copy back, export the
+// state -- while the caller's thread writes batch k-1 and reads batch k+1.  On the GPU the parse of batch k+1 (own
+// stream, does not depend on the MTF state) runs beside batch k's rank stage.  Bytes and callbacks leave block by
+// block, in stream order, on the caller's thread only.  ZLNG_PIPELINE=0 keeps everything on one context and thread.
 int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int level) {
     if (handler) {
         handler->SetInputterOutputter(inputter, outputter, true);
@@ -151,7 +152,8 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
     if (!bad_level) {
         const int nb = batch_blocks();
         const char* pe = getenv("ZLNG_PIPELINE");
-        const int nslots = (pe && atoi(pe) == 0) ? 1 : 2;
+        const bool pipelined = !(pe && atoi(pe) == 0);
+        const int nslots = pipelined ? 2 : 1;
         EncodeSlot slot[2];
         auto prepare = [&](EncodeSlot& s) {      // the second context is only created when a second batch exists
             if (s.ctx) return;
@@ -164,38 +166,51 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
         std::vector<unsigned char> state(ZLNG_MTF_STATE);
         int state_level = level;
         bool have_state = false, failed = false;
-        // finish the batch in `s`: import the stream state left by the previous batch, run the back half, emit
-        auto finish = [&](EncodeSlot& s) {
-            if (have_state) throw_rc(zlng_set_state(s.ctx, state.data(), state_level));
+        // GPU half of a batch (any thread; touches only its slot and the state hand-off, never the streams)
+        auto gpu_finish = [&](EncodeSlot* s) {
+            if (have_state) throw_rc(zlng_set_state(s->ctx, state.data(), state_level));
             size_t produced = 0;
-            throw_rc(zlng_encode_finish(s.ctx, s.out.data(), s.out.size(), &produced, s.ends.data()));
-            s.in_flight = false;
-            throw_rc(zlng_get_state(s.ctx, state.data(), &state_level));
+            throw_rc(zlng_encode_finish(s->ctx, s->out.data(), s->out.size(), &produced, s->ends.data()));
+            throw_rc(zlng_get_state(s->ctx, state.data(), &state_level));
             have_state = true;
+        };
+        // bytes, then the callback, block by block (src/libzling.cpp:273-283); caller's thread
+        auto emit = [&](EncodeSlot& s) {
             size_t prev = 0;
-            for (int b = 0; b < s.have; b++) {   // bytes, then the callback, block by block (src/libzling.cpp:273-283)
+            for (int b = 0; b < s.have; b++) {
                 if (!push_all(outputter, s.out.data() + prev, s.ends[(size_t)b] - prev)) { failed = true; return; }
                 prev = s.ends[(size_t)b];
                 if (handler) handler->OnProcess(s.in.data() + (size_t)b * kBlock, s.ilen[(size_t)b]);
             }
         };
+        std::future<void> pending;               // GPU half of the batch in slot[(k-1) % 2]
+        EncodeSlot* pending_slot = nullptr;
+        struct Joiner {                          // never leave the scope with the helper still using the slots
+            std::future<void>& f;
+            ~Joiner() { if (f.valid()) f.wait(); }
+        } joiner{pending};
         int k = 0;
         while (!failed && !inputter->IsEnd() && !inputter->IsErr()) {
             EncodeSlot& cur = slot[k % nslots];
-            EncodeSlot& prv = slot[(k + nslots - 1) % nslots];
-            if (cur.in_flight) finish(cur);      // one context only: nothing overlaps
-            if (failed) break;
             prepare(cur);
             if (!read_batch(inputter, cur, nb)) { failed = true; break; }
             if (cur.have == 0) break;
             throw_rc(zlng_encode_parse(cur.ctx, cur.in.data(), cur.total));
-            cur.in_flight = true;
-            if (nslots == 2 && prv.in_flight) finish(prv);
+            EncodeSlot* done = pending_slot;
+            if (pending.valid()) pending.get();                      // batch k-1 is back (rethrows its error)
+            if (pipelined) {
+                pending = std::async(std::launch::async, gpu_finish, &cur);
+                pending_slot = &cur;
+            } else {
+                gpu_finish(&cur);
+                done = &cur;
+            }
+            if (done) emit(*done);
             k++;
         }
-        for (int i = 0; i < nslots && !failed; i++) {      // drain, oldest first
-            EncodeSlot& s = slot[(k + i) % nslots];
-            if (s.in_flight && !inputter->IsErr()) finish(s);
+        if (pending.valid()) {
+            pending.get();
+            if (!failed && !inputter->IsErr()) emit(*pending_slot);
         }
     }
     if (handler) handler->OnDone();
