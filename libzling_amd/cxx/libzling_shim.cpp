@@ -10,6 +10,7 @@
 // block by block in stream order.
 #include <algorithm>
 #include <future>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -101,9 +102,18 @@ bool push_all(Outputter* out, unsigned char* p, size_t n) {       // src/libzlin
 }
 
 // One batch of blocks on its way through the GPU.
+// Uninitialised byte buffer: a std::vector would zero-fill gigabytes that a short stream never touches.
+struct RawBuf {
+    std::unique_ptr<unsigned char[]> p;
+    size_t n = 0;
+    void resize(size_t bytes) { p.reset(new unsigned char[bytes]); n = bytes; }
+    unsigned char* data() { return p.get(); }
+    size_t size() const { return n; }
+};
+
 struct EncodeSlot {
     zlng_ctx* ctx = nullptr;
-    std::vector<unsigned char> in, out;
+    RawBuf in, out;
     std::vector<size_t> ilen, ends;
     int have = 0;                 // blocks read into `in`
     size_t total = 0;             // their bytes
@@ -155,13 +165,17 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
         const bool pipelined = !(pe && atoi(pe) == 0);
         const int nslots = pipelined ? 2 : 1;
         EncodeSlot slot[2];
-        auto prepare = [&](EncodeSlot& s) {      // the second context is only created when a second batch exists
-            if (s.ctx) return;
-            s.ctx = make_ctx(level, true, nb);
+        // Host buffers first (their pages are only touched as far as the stream goes); the context -- whose device
+        // pools cost ~10 ms per block to create -- after the first batch is in, sized to it when the stream is short.
+        auto prepare_host = [&](EncodeSlot& s) {
+            if (s.in.size()) return;
             s.in.resize((size_t)nb * kBlock);
             s.out.resize(zlng_encode_bound((size_t)nb * kBlock));
             s.ilen.resize((size_t)nb);
             s.ends.resize((size_t)nb);
+        };
+        auto prepare_ctx = [&](EncodeSlot& s, bool stream_ended) {
+            if (!s.ctx) s.ctx = make_ctx(level, true, stream_ended ? std::max(s.have, 1) : nb);
         };
         std::vector<unsigned char> state(ZLNG_MTF_STATE);
         int state_level = level;
@@ -192,9 +206,10 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
         int k = 0;
         while (!failed && !inputter->IsEnd() && !inputter->IsErr()) {
             EncodeSlot& cur = slot[k % nslots];
-            prepare(cur);
+            prepare_host(cur);
             if (!read_batch(inputter, cur, nb)) { failed = true; break; }
             if (cur.have == 0) break;
+            prepare_ctx(cur, cur.have < nb || inputter->IsEnd());
             throw_rc(zlng_encode_parse(cur.ctx, cur.in.data(), cur.total));
             EncodeSlot* done = pending_slot;
             if (pending.valid()) pending.get();                      // batch k-1 is back (rethrows its error)
