@@ -586,11 +586,14 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             const uint32_t kix_w = canm ? kix : (uint32_t)kKeyTab, ctx_w = canm ? ctx : 256u;
             atomicOr(&keytab[kix_w], lane_bit);
             atomicOr(&ctxtab[ctx_w], lane_bit);
-            if (canm) {
-                if (level0) speculate_l0(S, dict, buf, heads, pos, qtext, ctx, hc, chk);
-                else speculate(S, dict, buf, heads, pos, cfg, qtext, ctx, hc, chk);
-            }
-            const uint32_t sp = S.sp, node0 = S.node0, head0 = S.head0, dmin = S.dmin;
+            // Level 0 speculates on every lane, live or not (no exec-mask region, no default values to materialise): a lane
+            // without room for a match (the last 275 bytes of the block) reads at most 354 bytes past the block -- the
+            // next block's text or the boundary's 512 readable bytes -- and everything derived from its result is
+            // gated by canm below.
+            if (level0) speculate_l0(S, dict, buf, heads, pos, qtext, ctx, hc, chk);
+            else if (canm) speculate(S, dict, buf, heads, pos, cfg, qtext, ctx, hc, chk);
+            const uint32_t sp = (level0 && !canm) ? (uint32_t)(kMatchMin - 1) : S.sp;
+            const uint32_t node0 = S.node0, head0 = S.head0, dmin = S.dmin;
             const uint32_t lkix1 = S.lkix1, lkix2 = S.lkix2, lctx1 = S.lctx1, lctx2 = S.lctx2;
             const bool lz1 = S.lz1, lz2 = S.lz2;
             if (prof) t1 = __builtin_readcyclecounter();
