@@ -7,6 +7,10 @@ import libzling_amd as zl
 from oracle_py import textgen, Oracle, Reference
 ref = Reference() if Reference.available() else Oracle()
 cases = [(256, 0, 1000), (256, 0, 2000), (192, 0, 3000), (96, 1, 4000), (96, 2, 5000), (64, 3, 6000), (64, 4, 7000)]
+if len(sys.argv) > 1:                    # python scripts/soak.py N: N further rounds of the same mix with other seeds
+    base = list(cases)
+    for r in range(1, int(sys.argv[1]) + 1):
+        cases += [(m, lv, sd + 17 * r) for m, lv, sd in base]
 rng = np.random.Generator(np.random.PCG64(77))
 bad = 0
 for mib, lv, seed in cases:
