@@ -30,6 +30,10 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+# per-file code generation options (measured on MI355X)
+PER_FILE_FLAGS = {}
+
+
 def build_hip(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "zlng.h")]
@@ -40,7 +44,8 @@ def build_hip(force=False, verbose=False):
         o = s[:-4] + ".o"
         if force or _stale(o, deps):
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-                   "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-c", s, "-o", o]
+                   "-Wall", "-Wno-unused-function", "-Wno-unused-value"] + PER_FILE_FLAGS.get(os.path.basename(s), []) + \
+                  os.environ.get("ZLNG_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
