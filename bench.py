@@ -5,19 +5,24 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole encode path (dictionary reset, ROLZ parse, MTF rank,
-histogram, Huffman lengths, layout, bit-pack + framing) over one 10^9-byte stream that is already
-resident in HBM, producing the complete .zlng in HBM.  Prints ONE JSON line on rank 0.
+One "step" = one pass of the whole encode path (dictionary reset, ROLZ parse, MTF rank, histogram,
+Huffman lengths, layout, bit-pack + framing) over this rank's block range, already resident in HBM,
+producing the complete .zlng bytes in HBM.  Prints ONE JSON line on rank 0.
 
-Workload: real enwik9 if $ZLNG_ENWIK9 (or ./enwik9) exists, otherwise the deterministic synthetic
-text of libzling_amd/host/textgen.c at the same size (`data` says which).
+Workload: real enwik9 if $ZLNG_ENWIK9 (or ./enwik9, ./enwik8 for --size 100000000) exists, otherwise the
+deterministic synthetic text of libzling_amd/host/textgen.c at the same size (`data` says which).
 
-Multi-GPU (--shard streams, default): every rank encodes its own 10^9-byte stream (weak scaling,
-no data-path collective).  --shard single-stream instead shards ONE N x 10^9-byte stream by block
-ranges: each rank parses its range at once, the 64 KiB MTF state is handed from rank r to r+1 over
-RCCL (blocks of one stream are not independent), then rank + Huffman run per rank.
+N > 1 (default --shard single-stream): ONE stream of N x --size bytes, sharded by contiguous block ranges
+(SURVEY 8(e)): every rank parses its range at once; the 64 KiB MTF tables + current_level then travel rank
+r -> r+1 over RCCL (blocks of one stream are not independent) and rank + Huffman run rank by
+rank; the ranks' bytes concatenate to the single-device stream.  Per-GPU work is fixed ("weak"), and the
+JSON carries the Amdahl terms (`amdahl`: parse, N x rank, Huffman) because the rank chain does not shard.
+--shard streams (one independent stream per rank) is kept as a labelled extra, never the headline.
+
+--decode times the inverse path (BASELINE config 5) on the same stream instead and prints its own line.
 """
 import argparse
+import glob
 import hashlib
 import json
 import os
@@ -33,32 +38,81 @@ import torch
 import torch.distributed as dist
 
 import libzling_amd as zl
+from libzling_amd import sharding
 
 BLOCK = zl.BLOCK
 METRIC = "encode MB/s (input) at e0 on enwik9; bit-exact .zlng; 1/2/4/8 GPU"
+METRIC_DECODE = "decode MB/s (output) of the e0 enwik9 .zlng; bit-exact round trip; 1 GPU"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_OF_STAGE = {"rolz_parse": "k_rolz_parse_wave", "mtf_rank": "k_mtf_dense", "huff_pack": "k_pack", "huff_lengths": "k_lengths",
+                   "histogram": "k_histogram", "huff_decode": "k_huff_decode", "rolz_decode": "k_rolz_decode", "frame_walk": "k_frame_walk"}
+
+
+def kernel_source_sha():
+    """Identity of the kernels a profile was taken on (the GPU box has no .git): SHA-256 over the csrc sources."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_input(n, first_chunk):
     """(array, source)."""
-    path = os.environ.get("ZLNG_ENWIK9", os.path.join(ROOT, "enwik9"))
-    if os.path.exists(path) and first_chunk == 0 and os.path.getsize(path) >= n:
-        return np.fromfile(path, dtype=np.uint8, count=n), "enwik9"
+    cands = [os.environ.get("ZLNG_ENWIK9"), os.path.join(ROOT, "enwik9")]
+    if n <= 100_000_000:
+        cands += [os.environ.get("ZLNG_ENWIK8"), os.path.join(ROOT, "enwik8")]
+    for path in cands:
+        if path and os.path.exists(path) and first_chunk == 0 and os.path.getsize(path) >= n:
+            return np.fromfile(path, dtype=np.uint8, count=n), os.path.basename(path)
     from oracle_py import textgen      # generator lives in libzling_amd/host; oracle_py only binds it
     return textgen(n, first_chunk), "synthetic"
 
 
-def cpu_baseline(sample):
-    """Reference CPU encoder on `sample` bytes, 1 thread: (MB/s, kind, zlng)."""
+def cpu_encoder():
     from oracle_py import Oracle, Reference
-    if Reference.available():
-        enc, kind = Reference(), "reference"
-    else:
-        enc, kind = Oracle(), "port"
-    t = time.perf_counter()
-    z = enc.encode(sample, 0)
-    dt = time.perf_counter() - t
-    return sample.size / dt / 1e6, kind, z
+    return (Reference(), "reference") if Reference.available() else (Oracle(), "port")
+
+
+def traffic_of(kernel, size, level, source, world):
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes -- only if they were taken on these very
+    kernel sources and this workload; rocprofv3 cannot run inside this process."""
+    try:
+        tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        pj = json.load(open(tfile))
+        wl = pj["workload"]
+        if pj.get("kernel_source_sha") != kernel_source_sha():
+            return None, "stale: %s was taken on other kernel sources" % os.path.basename(tfile)
+        if world == 1 and wl["bytes"] == size and wl["level"] == level and source == "synthetic":
+            return pj["kernels"][kernel]["hbm_bytes_corrected"], \
+                "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, (2*FETCH+WRITE)*1024, same kernel sources)" % os.path.basename(tfile)
+    except Exception:
+        pass
+    return None, None
+
+
+def rank_chain_line(x, level, hot_literals_gpu, mtf_ms):
+    """ns per literal of the hottest context's serial rank chain (src/libzling_lz.cpp:112-117): on the GPU (stage time / that
+    context's literals -- the stage is bounded by its longest chain) and on one host core (the reference's own
+    ZlingMTFEncoder over the same context's literals of the first 32 MiB)."""
+    from oracle_py import Oracle, Reference
+    o = Oracle()
+    lits = []
+    for b in range(min(2, (x.size + BLOCK - 1) // BLOCK)):
+        tok, _ = o.parse_block(x[b * BLOCK:(b + 1) * BLOCK], level)
+        sym, aux = tok & 0xFFFF, tok >> 16
+        lits.append((aux[(sym < 256) & (aux < 256)].astype(np.uint8), sym[(sym < 256) & (aux < 256)].astype(np.uint8)))
+    ctx = np.concatenate([c for c, _ in lits]); byt = np.concatenate([b for _, b in lits])
+    hot = int(np.argmax(np.bincount(ctx, minlength=256)))
+    seq = np.ascontiguousarray(byt[ctx == hot])
+    host_ns = None
+    if Reference.available() and seq.size:
+        r = Reference()
+        r.mtf_chain(seq[:1000])
+        t = time.perf_counter(); r.mtf_chain(seq); host_ns = (time.perf_counter() - t) / seq.size * 1e9
+    return {"context": hot, "literals_gpu": int(hot_literals_gpu), "gpu_ns_per_literal": round(mtf_ms * 1e6 / max(hot_literals_gpu, 1), 2),
+            "host_ns_per_literal": None if host_ns is None else round(host_ns, 2), "host_sample_literals": int(seq.size),
+            "note": "one serial chain per context over the whole stream; the hottest context bounds the stage on any number of GPUs"}
 
 
 def main():
@@ -66,11 +120,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=1_000_000_000, help="bytes per stream (enwik9 = 10^9)")
+    ap.add_argument("--size", type=int, default=1_000_000_000, help="bytes per GPU (enwik9 = 10^9)")
     ap.add_argument("--level", type=int, default=0)
-    ap.add_argument("--shard", choices=["streams", "single-stream"], default="streams")
+    ap.add_argument("--shard", choices=["single-stream", "streams"], default="single-stream")
+    ap.add_argument("--ctx-blocks", type=int, default=128, help="blocks per context (a rank uses as many contexts as its range needs)")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,9 +148,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.decode:
+        return bench_decode(args, world, rank, local)
 
     # ---- this rank's share of the workload
-    from libzling_amd import sharding
     single = args.shard == "single-stream" and world > 1
     if single:
         off, n = sharding.plan(args.size * world, world, per_rank_bytes=args.size)[rank]
@@ -107,111 +164,183 @@ def main():
     d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
     d_in[:n].copy_(torch.from_numpy(x))
     d_in[n:].zero_()
-    cap = zl.encode_bound(n)
+    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(local, args.level, True, blocks), nb, min(240, args.ctx_blocks))
+    cap = zl.encode_bound(n) + 4 * len(enc.parts)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    d_state = torch.empty(zl.MTF_STATE, dtype=torch.uint8, device="cuda")
-    h_state = torch.empty(zl.MTF_STATE, dtype=torch.uint8) if one_dev else None
-    stream = zl.Stream(local, args.level, True, nb)
-    init_state, init_level = stream.get_state()
+    d_state = torch.empty(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
+    init_state, init_level = enc.streams[0].get_state()
+    d_state0 = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
+    d_state0[:zl.MTF_STATE].copy_(torch.from_numpy(init_state))
+    h_state = torch.empty(sharding.STATE_BUF, dtype=torch.uint8) if one_dev else None
+
+    def finish(level):
+        return enc.finish(d_out.data_ptr(), cap, d_state.data_ptr(), level)
+
+    def load_state(buf):                                             # received buffer -> this rank's entry state
+        if one_dev:
+            d_state.copy_(buf)
+        torch.cuda.synchronize()                                     # the receive / copy ran on torch's streams
+        return int(buf[zl.MTF_STATE].item())
+
+    def store_state(buf, level):                                     # exit state (already in d_state) -> buffer to send
+        d_state[zl.MTF_STATE] = level
+        if one_dev:
+            buf.copy_(d_state.cpu())
 
     def step():
         if single:
-            if one_dev:                                            # gloo moves host tensors
-                def to_buf(b):
-                    lv = stream.get_state_device(d_state.data_ptr()); b.copy_(d_state.cpu()); return lv
-                def from_buf(b, lv):
-                    d_state.copy_(b); torch.cuda.synchronize(); stream.set_state_device(d_state.data_ptr(), lv)
-                buf = h_state
-            else:
-                to_buf = lambda b: stream.get_state_device(b.data_ptr())
-                from_buf = lambda b, lv: (torch.cuda.synchronize(), stream.set_state_device(b.data_ptr(), lv))
-                buf = d_state
-            return sharding.run_handoff(
-                stream, rank, world, dist, buf, init_state, init_level, args.level,
-                parse=lambda: stream.parse_device(d_in.data_ptr(), n),
-                finish=lambda: stream.finish_device(d_out.data_ptr(), cap),
-                state_to_buf=to_buf, buf_to_state=from_buf)
-        stream.set_state(init_state, init_level)                   # a fresh stream every step
-        return stream.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+            if rank == 0:
+                d_state.copy_(d_state0); torch.cuda.synchronize()
+            return sharding.run_handoff(enc, rank, world, dist, h_state if one_dev else d_state,
+                                        parse=lambda: enc.parse(d_in.data_ptr(), n), finish=finish,
+                                        load_state=load_state, store_state=store_state, initial_level=init_level)
+        d_state.copy_(d_state0); torch.cuda.synchronize()           # a fresh stream every step
+        enc.parse(d_in.data_ptr(), n)
+        return finish(init_level)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    out_len = 0
+    segs = []
     for _ in range(args.warmup):
-        out_len = step()
+        segs, _lv = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out_len = step()
+        segs, _lv = step()
     fence()
     dt = time.perf_counter() - t0
-    stage = dict(stream.timings())
+    out_len = sum(k for _, k in segs)
+    stage = enc.timings()
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        sizes = torch.tensor([float(n), float(out_len)], dtype=torch.float64, device=cdev)
-        dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
-        total_in, total_out = float(sizes[0].item()), float(sizes[1].item())
+        sums = torch.tensor([float(n), float(out_len), stage.get("mtf_rank", 0.0),
+                             sum(stage.get(k, 0.0) for k in ("histogram", "huff_lengths", "layout_scan", "huff_pack"))], dtype=torch.float64, device=cdev)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        mx = torch.tensor([stage.get("rolz_parse_max", 0.0)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        total_in, total_out, rank_sum, huff_sum, parse_max = (float(sums[0]), float(sums[1]), float(sums[2]), float(sums[3]), float(mx[0]))
     else:
         total_in, total_out = float(n), float(out_len)
+        rank_sum = stage.get("mtf_rank", 0.0)
+        huff_sum = sum(stage.get(k, 0.0) for k in ("histogram", "huff_lengths", "layout_scan", "huff_pack"))
+        parse_max = stage.get("rolz_parse_max", 0.0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_in * args.steps / dt / 1e6
-        # dominant kernel of the last step, from the HIP events the library records on its stream
-        dom = max(stage, key=stage.get) if stage else None
-        dom_ms = stage.get(dom, 0.0) if dom else 0.0
+        # dominant kernel of the last step on this rank, from the HIP events the library records on its own streams
+        real = {k: v for k, v in stage.items() if k != "rolz_parse_max"}
+        dom = max(real, key=real.get) if real else None
+        dom_ms = real.get(dom, 0.0) if dom else 0.0
         alg_bytes = float(n) + float(out_len)                       # every input byte read once,
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0   # every .zlng byte written once
-        # HBM traffic of the dominant kernel per launch from the committed PMC passes (profiles/), when they
-        # were taken on this same workload; rocprofv3 cannot run inside this process
-        traffic = None
-        tsrc = None
-        kmap = {"rolz_parse": "k_rolz_parse_wave", "mtf_rank": "k_mtf_dense", "huff_pack": "k_pack"}
-        try:
-            import glob
-            tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]      # newest committed pass
-            pj = json.load(open(tfile))
-            wl = pj["workload"]
-            if world == 1 and wl["bytes"] == args.size and wl["level"] == args.level and source == "synthetic":
-                traffic = pj["kernels"][kmap[dom]]["hbm_bytes_corrected"]
-                tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, (2*FETCH+WRITE)*1024)" % os.path.basename(tfile)
-        except Exception:
-            pass
+        traffic, tsrc = traffic_of(KERNEL_OF_STAGE.get(dom, dom), args.size, args.level, source, world)
         res = {
             "metric": METRIC, "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": source,
-            "config": {"workload": "enwik9-shaped %s text, %d B per stream, level e%d, %d blocks of 16 MiB in flight per GPU"
-                       % (source, args.size, args.level, nb),
-                       "shard": ("one stream sharded by block range, MTF state hand-off over RCCL" if single
-                                 else "one independent stream per GPU"),
+            "config": {"workload": "enwik9-shaped %s text, %d B per GPU, level e%d, %d blocks of 16 MiB in flight per GPU (%d context%s)"
+                       % (source, args.size, args.level, nb, len(enc.parts), "" if len(enc.parts) == 1 else "s"),
+                       "shard": ("ONE stream of %d B sharded by contiguous block ranges; MTF tables + current_level handed rank to rank over RCCL" % int(total_in)
+                                 if single else ("one stream on one GPU" if world == 1 else "EXTRA, not the metric: one independent stream per GPU")),
                        "input_bytes_total": int(total_in), "zlng_bytes_total": int(total_out)},
-            "roofline": {"bound": "hbm", "kernel": "%s (stage %s)" % (kmap.get(dom, dom), dom), "kernel_ms": round(dom_ms, 3),
+            "roofline": {"bound": "hbm", "kernel": "%s (stage %s)" % (KERNEL_OF_STAGE.get(dom, dom), dom), "kernel_ms": round(dom_ms, 3),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": tsrc,
-                         "algorithmic_bytes": int(alg_bytes)},
+                         "algorithmic_bytes": int(alg_bytes), "kernel_source_sha": kernel_source_sha()},
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+            # what bounds the sharded stream: the parses run side by side, the rank chains one after the other
+            "amdahl": {"parse_ms_max_over_ranks": round(parse_max, 3), "rank_ms_sum_over_ranks": round(rank_sum, 3),
+                       "huffman_ms_sum_over_ranks": round(huff_sum, 3),
+                       "model_ms": round(parse_max + rank_sum + huff_sum, 3) if single or world == 1 else None},
         }
+        got = np.concatenate([d_out[o:o + k].cpu().numpy() for o, k in segs]) if segs else np.empty(0, np.uint8)
         if not args.no_cpu_baseline and world == 1:
+            # host-to-host entry point (pageable H2D of the input + D2H of the .zlng inside the call), SURVEY 8(d)
+            if nb <= 240:
+                with zl.Stream(local, args.level, True, nb) as hs:
+                    out_h = np.zeros(zl.encode_bound(n), np.uint8)          # pages touched before the timed call
+                    hs.encode_into(x, out_h)
+                    hs.set_state(init_state, init_level)
+                    t1 = time.perf_counter(); nh = hs.encode_into(x, out_h); th = time.perf_counter() - t1
+                    res["value_host"] = round(n / th / 1e6, 2)
+                    res["host_note"] = ("zlng_encode_blocks: pageable host input -> host .zlng, PCIe copies inside the call; "
+                                        "identical bytes: %s" % bool(nh == got.size and np.array_equal(out_h[:nh], got)))
             sample_n = min(n, (args.cpu_sample_mib << 20) // BLOCK * BLOCK) or n
-            mbs, kind, z = cpu_baseline(x[:sample_n])
-            got = d_out[: z.size].cpu().numpy()
+            cpu, kind = cpu_encoder()
+            t1 = time.perf_counter(); z = cpu.encode(x[:sample_n], args.level); tc = time.perf_counter() - t1
             # the .zlng of a whole-block prefix is a prefix of the stream's .zlng (state only flows forward)
-            res["parity"] = bool(np.array_equal(got, z))
-            res["cpu_baseline"] = {"value": round(mbs, 2), "unit": "MB/s", "cores": 1, "kind": kind,
+            res["parity"] = bool(np.array_equal(got[: z.size], z))
+            res["cpu_baseline"] = {"value": round(sample_n / tc / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": kind,
                                    "sample": "first %d MiB of the same stream, e%d, single thread, "
                                              "GPU output prefix compared byte-for-byte" % (sample_n >> 20, args.level)}
-        res["zlng_sha256_rank0"] = hashlib.sha256(d_out[:out_len].cpu().numpy().tobytes()).hexdigest()
+            hot = enc.streams[-1].debug_fetch(8, 0, np.uint32, 256)
+            if len(enc.parts) == 1 and args.level == 0:
+                res["rank_chain"] = rank_chain_line(x, args.level, int(hot.max()), stage.get("mtf_rank", 0.0))
+        res["zlng_sha256_rank0"] = hashlib.sha256(got.tobytes()).hexdigest()
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_decode(args, world, rank, local):
+    """BASELINE config 5: the e0 .zlng of the stream -> bytes, on one GPU (the replay is stream-serial: it does not shard)."""
+    n = args.size
+    x, source = load_input(n, 0)
+    nb = (n + BLOCK - 1) // BLOCK
+    with zl.Stream(local, args.level, True, nb) as s:
+        z = s.encode(x)
+        ends = list(s.block_ends)
+    d_z = torch.empty(z.size + 512, dtype=torch.uint8, device="cuda")
+    d_z[: z.size].copy_(torch.from_numpy(z)); d_z[z.size:].zero_()
+    d_raw = torch.empty(nb * BLOCK + 512, dtype=torch.uint8, device="cuda")
+    dec = zl.Stream(local, 0, False, nb)
+    init_state, init_level = dec.get_state()
+
+    def step():
+        dec.set_state(init_state, 0)
+        return dec.decode_device(d_z.data_ptr(), z.size, d_raw.data_ptr(), nb * BLOCK)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        used, produced = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stage = dict(dec.timings())
+    dom = max(stage, key=stage.get)
+    alg = float(z.size + n)
+    achieved = alg / (stage[dom] * 1e-3) / 1e9
+    ok = produced == n and used == z.size and bool(torch.equal(d_raw[:n].cpu(), torch.from_numpy(x)))
+    res = {"metric": METRIC_DECODE, "value": round(n * args.steps / dt / 1e6, 2), "unit": "MB/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8", "data": source,
+           "config": {"workload": "decode of the e%d .zlng (%d B) of enwik9-shaped %s text, %d B, %d blocks" % (args.level, z.size, source, n, nb)},
+           "roofline": {"bound": "hbm", "kernel": "%s (stage %s)" % (KERNEL_OF_STAGE.get(dom, dom), dom), "kernel_ms": round(stage[dom], 3),
+                        "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                        "traffic": None, "algorithmic_bytes": int(alg)},
+           "stage_ms": {k: round(v, 3) for k, v in stage.items()}, "round_trip": ok}
+    if not args.no_cpu_baseline:
+        from oracle_py import Oracle, Reference
+        nblk_s = max(1, min(nb, (args.cpu_sample_mib << 20) // BLOCK))
+        zs = z[: ends[nblk_s - 1]]
+        want = min(n, nblk_s * BLOCK)
+        if Reference.available():
+            r = Reference(); t1 = time.perf_counter(); rc, y, _m = r.decode(zs, want); tc = time.perf_counter() - t1; kind = "reference"
+        else:
+            o = Oracle(); t1 = time.perf_counter(); rc, y = o.decode(zs, want); tc = time.perf_counter() - t1; kind = "port"
+        res["cpu_baseline"] = {"value": round(want / tc / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": kind,
+                               "sample": "the first %d blocks of the same .zlng, single thread; output == input: %s" % (nblk_s, bool(rc == 0 and np.array_equal(y, x[:want])))}
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -72,7 +72,9 @@ int zlng_device_count(void);
 /* Create a stream context on HIP device `device`.  level 0..4 (ignored for decode).
  * max_blocks = largest number of 16 MiB blocks a single call will pass (sizes the HBM pools; 1..240 --
  * longer streams are fed in several calls, the stream state is carried by the context).
- * Returns NULL on error; *err (optional) receives the code. */
+ * Returns NULL on error; *err (optional) receives the code.
+ * A call that fails (ZLNG_E_CAP, ZLNG_E_PAYLOAD, ZLNG_E_DEVICE ...) leaves the stream state -- MTF tables and
+ * current_level -- as it found it, so it can be repeated, e.g. with a larger output buffer. */
 zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int* err);
 void      zlng_destroy(zlng_ctx*);
 
@@ -106,12 +108,33 @@ int zlng_encode_finish_device(zlng_ctx*, void* d_out, size_t out_cap, size_t* ou
 int zlng_encode_parse(zlng_ctx*, const uint8_t* in, size_t in_len);
 int zlng_encode_finish(zlng_ctx*, uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
 
-/* Stream state hand-off: 65,536 bytes of MTF tables (context-major) + current_level. */
+/* Stream state hand-off: 65,536 bytes of MTF tables (context-major) + current_level (0, or the context's level:
+ * src/libzling.cpp:261-266 -- anything else is rejected). */
 int zlng_get_state(zlng_ctx*, uint8_t mtf[ZLNG_MTF_STATE], int* current_level);
 int zlng_set_state(zlng_ctx*, const uint8_t mtf[ZLNG_MTF_STATE], int current_level);
 /* Same with the 65,536 table bytes in this device's HBM (e.g. the buffer of an RCCL send/recv). */
 int zlng_get_state_device(zlng_ctx*, void* d_mtf, int* current_level);
 int zlng_set_state_device(zlng_ctx*, const void* d_mtf, int current_level);
+
+/* ---- one stream over several devices (replaces the same reference call sites as zlng_encode_blocks) ----
+ * A group owns one encode context per entry of `devices` (a device may be listed more than once: several contexts per
+ * GPU).  One call takes up to members x max_blocks_per_member blocks of ONE stream: contiguous block ranges are copied
+ * to and parsed on all members at once; rank + Huffman then run member by member in stream order with the 64 KiB MTF
+ * tables and current_level handed from one member to the next, because the reference carries both through the whole
+ * stream (src/libzling.cpp:185, 197, 261-266; src/libzling_lz.cpp:197-209).  The bytes are exactly those of a
+ * single-context encode.  The stream state lives in the group between calls.  After a failed finish the group's state
+ * is unchanged and the range has to be submitted again. */
+typedef struct zlng_group zlng_group;
+zlng_group* zlng_group_create(const int* devices, int ndev, int level, int max_blocks_per_member, int* err);
+void        zlng_group_destroy(zlng_group*);
+int         zlng_group_members(const zlng_group*);
+size_t      zlng_group_capacity(const zlng_group*);      /* input bytes one call may pass */
+int zlng_group_encode_blocks(zlng_group*, const uint8_t* in, size_t in_len,
+                             uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+int zlng_group_encode_parse(zlng_group*, const uint8_t* in, size_t in_len);      /* returns when the copies are staged */
+int zlng_group_encode_finish(zlng_group*, uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+int zlng_group_get_state(zlng_group*, uint8_t mtf[ZLNG_MTF_STATE], int* current_level);
+int zlng_group_set_state(zlng_group*, const uint8_t mtf[ZLNG_MTF_STATE], int current_level);
 
 /* Decode a stream prefix made of whole blocks from HOST memory; *in_used gets the bytes consumed. */
 int zlng_decode_blocks(zlng_ctx*, const uint8_t* in, size_t in_len, size_t* in_used,

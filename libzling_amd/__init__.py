@@ -78,6 +78,17 @@ def lib():
         L.zlng_stream.argtypes = [C.c_void_p]
         L.zlng_strerror.restype = C.c_char_p
         L.zlng_strerror.argtypes = [C.c_int]
+        L.zlng_group_create.restype = C.c_void_p
+        L.zlng_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.zlng_group_destroy.argtypes = [C.c_void_p]
+        L.zlng_group_members.argtypes = [C.c_void_p]
+        L.zlng_group_capacity.restype = C.c_size_t
+        L.zlng_group_capacity.argtypes = [C.c_void_p]
+        L.zlng_group_encode_blocks.argtypes = [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t, _szp, _szp]
+        L.zlng_group_encode_parse.argtypes = [C.c_void_p, _u8p, C.c_size_t]
+        L.zlng_group_encode_finish.argtypes = [C.c_void_p, _u8p, C.c_size_t, _szp, _szp]
+        L.zlng_group_get_state.argtypes = [C.c_void_p, _u8p, C.POINTER(C.c_int)]
+        L.zlng_group_set_state.argtypes = [C.c_void_p, _u8p, C.c_int]
         _lib = L
     return _lib
 
@@ -133,6 +144,17 @@ class Stream:
         self.block_ends = list(ends)[:nb]
         return out[: n.value].copy()
 
+    def encode_into(self, a, out):
+        """Host entry point with caller-owned buffers (no allocation inside the call): bytes written."""
+        n = C.c_size_t(0)
+        nb = (a.size + BLOCK - 1) // BLOCK
+        ends = (C.c_size_t * max(nb, 1))()
+        rc = lib().zlng_encode_blocks(self._h, _ptr(a) if a.size else None, a.size, _ptr(out), out.size, C.byref(n), ends)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_encode_blocks")
+        self.block_ends = list(ends)[:nb]
+        return n.value
+
     def decode(self, z, cap):
         a = np.ascontiguousarray(np.frombuffer(bytes(z), np.uint8) if not isinstance(z, np.ndarray) else z)
         out = np.empty(max(cap, 1), np.uint8)
@@ -154,6 +176,17 @@ class Stream:
             raise ZlngError(rc, "zlng_encode_blocks_device")
         self.block_ends = list(ends)[:nb]
         return n.value
+
+    def decode_device(self, d_in, in_len, d_out, out_cap):
+        """(compressed bytes consumed, bytes produced); self.block_ends = end offset of every decoded block."""
+        n = C.c_size_t(0)
+        used = C.c_size_t(0)
+        ends = (C.c_size_t * max(self.max_blocks, 1))()
+        rc = lib().zlng_decode_blocks_device(self._h, d_in, in_len, C.byref(used), d_out, out_cap, C.byref(n), ends)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_decode_blocks_device")
+        self.block_ends = list(ends)
+        return used.value, n.value
 
     def parse_device(self, d_in, in_len):
         rc = lib().zlng_encode_parse_device(self._h, d_in, in_len)
@@ -203,6 +236,25 @@ class Stream:
             raise ZlngError(rc, "zlng_debug_fetch")
         return out
 
+    def debug_lengths(self, freq):
+        """Test hook (zlng_debug_lengths): K4 on caller-supplied rows of 546 counts -> (lens u8, codes u16)."""
+        freq = np.ascontiguousarray(freq, np.uint32)
+        assert freq.ndim == 2 and freq.shape[1] == 546
+        lens = np.empty(freq.shape, np.uint8)
+        codes = np.empty(freq.shape, np.uint16)
+        f = lib().zlng_debug_lengths
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        rc = f(self._h, freq.ctypes.data, freq.shape[0], lens.ctypes.data, codes.ctypes.data)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_debug_lengths")
+        return lens, codes
+
+    def passes(self):
+        """Test hook: parse passes the last encode needed (1 = no level-schedule repair, no pool growth)."""
+        f = lib().zlng_debug_passes
+        f.argtypes = [C.c_void_p]
+        return f(self._h)
+
     def block_tokens(self, blk):
         ntok, nsub = self.debug_fetch(5, blk, np.uint32, 2)
         tok = self.debug_fetch(0, blk, np.uint32, int(ntok))
@@ -217,6 +269,63 @@ class Stream:
 
     def hip_stream(self):
         return lib().zlng_stream(self._h)
+
+
+class Group:
+    """One zlng_group: ONE stream over several contexts / devices (contiguous block ranges, state handed member to member)."""
+
+    def __init__(self, devices, level=0, blocks_per_member=8):
+        err = C.c_int(0)
+        arr = (C.c_int * len(devices))(*devices)
+        self._h = lib().zlng_group_create(arr, len(devices), level, blocks_per_member, C.byref(err))
+        if not self._h:
+            raise ZlngError(err.value, "zlng_group_create")
+        self.level = level
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.zlng_group_destroy(h)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def encode(self, data, split=False):
+        a = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data)
+        cap = encode_bound(a.size)
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        nb = (a.size + BLOCK - 1) // BLOCK
+        ends = (C.c_size_t * max(nb, 1))()
+        if split:
+            rc = lib().zlng_group_encode_parse(self._h, _ptr(a), a.size)
+            if rc == 0:
+                rc = lib().zlng_group_encode_finish(self._h, _ptr(out), cap, C.byref(n), ends)
+        else:
+            rc = lib().zlng_group_encode_blocks(self._h, _ptr(a) if a.size else None, a.size, _ptr(out), cap, C.byref(n), ends)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_group_encode")
+        self.block_ends = list(ends)[:nb]
+        return out[: n.value].copy()
+
+    def get_state(self):
+        buf = np.empty(MTF_STATE, np.uint8)
+        lv = C.c_int(0)
+        rc = lib().zlng_group_get_state(self._h, _ptr(buf), C.byref(lv))
+        if rc != 0:
+            raise ZlngError(rc, "zlng_group_get_state")
+        return buf, lv.value
+
+    def set_state(self, mtf, level):
+        mtf = np.ascontiguousarray(mtf, np.uint8)
+        rc = lib().zlng_group_set_state(self._h, _ptr(mtf), level)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_group_set_state")
 
 
 def encode(data, level=0, device=0):

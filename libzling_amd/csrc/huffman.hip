@@ -19,12 +19,12 @@ __device__ __forceinline__ uint32_t sub_index(uint32_t blk, uint32_t sub) { retu
 // 256 lanes stream the sub-block's token words (coalesced) and count into LDS.
 __global__ __launch_bounds__(256) void k_histogram(HuffArgs a) {
     __shared__ uint32_t h[kNsymAll];
-    const uint32_t blk = blockIdx.y, sub = blockIdx.x;
+    const uint32_t blk = blockIdx.y + a.blk0, sub = blockIdx.x;
     if (sub >= a.nsub[blk]) return;
     for (uint32_t i = threadIdx.x; i < kNsymAll; i += 256) h[i] = 0;
     __syncthreads();
     const SubCut c = a.cuts[sub_index(blk, sub)];
-    const uint32_t* t = a.tok + (size_t)blk * kTokCap;
+    const uint32_t* t = a.tok + (size_t)blk * a.tok_cap;
     for (uint32_t i = c.tok_begin + threadIdx.x; i < c.tok_end; i += 256) {
         const uint32_t v = t[i], sym = v & 0xFFFF;
         atomicAdd(&h[sym], 1u);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void k_lengths(HuffArgs a) {
     __shared__ uint32_t heap[kNsym1];
     __shared__ uint16_t kid0[2 * kNsym1], kid1[2 * kNsym1], leafsym[kNsym1];
     __shared__ uint8_t  depth[2 * kNsym1];
-    const uint32_t blk = blockIdx.y, sub = blockIdx.x;
+    const uint32_t blk = blockIdx.y + a.blk0, sub = blockIdx.x;
     if (sub >= a.nsub[blk]) return;
     const uint32_t si = sub_index(blk, sub);
     const uint32_t lane = threadIdx.x;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(1024) void k_layout(HuffArgs a) {
     }
     if (tid == 0) {
         a.summary[0] = carry;
-        a.summary[1] = err | (carry > a.out_cap ? 4u : 0u);
+        a.summary[1] = err | (carry > a.out_cap ? 4u : 0u) | (*a.overflow ? 8u : 0u);
     }
 }
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack(HuffArgs a) {
     cur += 8ull * (kHeaderBytes + kTableBytes);
     __syncthreads();
 
-    const uint32_t* t = a.tok + (size_t)blk * kTokCap;
+    const uint32_t* t = a.tok + (size_t)blk * a.tok_cap;
     for (uint32_t base = c.tok_begin; ; base += kPackTile) {
         // flush completed words, slide the window
         cur = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cur >> 32)) << 32) |
@@ -351,10 +351,10 @@ __global__ __launch_bounds__(kPackThreads) void k_pack(HuffArgs a) {
 }
 
 void launch_histogram(const HuffArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_histogram, dim3(kMaxSub, a.nblocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_histogram, dim3(kMaxSub, a.nblocks - a.blk0), dim3(256), 0, s, a);
 }
 void launch_lengths(const HuffArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_lengths, dim3(kMaxSub, a.nblocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_lengths, dim3(kMaxSub, a.nblocks - a.blk0), dim3(64), 0, s, a);
 }
 void launch_layout(const HuffArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, s, a);

@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uin
 // statement that reads it.  The lane values here are SALU results (s_ff1 / s_mul / s_lshr), so the
 // "VALU-written SGPR as lane select" wait states are not owed; SALU -> M0 -> v_writelane needs none.
 __device__ __forceinline__ void wrl(uint32_t& v, uint32_t val, uint32_t lane) {
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane));
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane) : "m0");
 }
 
 // per-lane select by a wave-uniform 64-bit lane mask held in an SGPR pair: lane l gets (mask bit l) ? b : a.
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void k_lit_tiles(MtfArgs a) {
         mask[c] = 0;
     }
     __syncthreads();
-    uint32_t* t = a.tok + (size_t)blk * kTokCap;
+    uint32_t* t = a.tok + (size_t)blk * a.tok_cap;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t ch = 0; ch < kLitTile / 64; ch++) {
         const uint32_t idx = tile * kLitTile + ch * 64 + lane;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
           [p4] "s"(pk[4]), [p5] "s"(pk[5]), [p6] "s"(pk[6]), [p7] "s"(pk[7]), [p8] "s"(pk[8]), [p9] "s"(pk[9]), \
           [p10] "s"(pk[10]), [p11] "s"(pk[11]), [p12] "s"(pk[12]), [p13] "s"(pk[13]), [p14] "s"(pk[14]),        \
           [p15] "s"(pk[15])                                                                                     \
-        : "vcc", "scc", "s98", "s99")
+        : "vcc", "scc", "s98", "s99", "m0")
 
 __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     const uint32_t ctx = blockIdx.x;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
 }
 
 void launch_mtf_rank(const MtfArgs& a, hipStream_t s) {
-    const dim3 tiles((unsigned)(kTokCap / kLitTile), a.nblocks);
+    const dim3 tiles((unsigned)(a.tok_cap / kLitTile), a.nblocks);
     hipLaunchKernelGGL(k_lit_tile_base, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_lit_tiles<kModeHist>, tiles, dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_lit_scan, dim3(256), dim3(256), 0, s, a);

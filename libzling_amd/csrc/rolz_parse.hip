@@ -133,13 +133,13 @@ __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, i
 __global__ __launch_bounds__(64) void k_rolz_parse_serial(ParseArgs a) {
     __shared__ uint16_t heads[256];
     __shared__ uint32_t mru[256];          // slot0 in bits 0..15, slot1 in bits 16..31
-    const uint32_t blk = blockIdx.x;
+    const uint32_t blk = blockIdx.x + a.blk0;
     const size_t base = (size_t)blk * kBlockIn;
     if (base >= a.in_len) return;
     const uint8_t* buf = a.in + base;
     const int ilen = (int)((a.in_len - base) < (size_t)kBlockIn ? (a.in_len - base) : (size_t)kBlockIn);
     uint8_t* dict = a.dict + (size_t)blk * kDictBytes;
-    uint32_t* tok = a.tok + (size_t)blk * kTokCap;
+    uint32_t* tok = a.tok + (size_t)blk * a.tok_cap;
     SubCut* cuts = a.cuts + (size_t)blk * kMaxSub;
 
     for (int i = threadIdx.x; i < 256; i += 64) heads[i] = 0;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(64) void k_rolz_parse_serial(ParseArgs a) {
         if (ipos == 0 && ipos < ilen) { tok[nt++] = buf[ipos++] | kTokRawCtx << 16; opos++; }
         if (ipos == 1 && ipos < ilen) { tok[nt++] = buf[ipos++] | kTokRawCtx << 16; opos++; }
         while (opos + 1 < kSubSyms && ipos < ilen) {
+            if (nt + 1 > a.tok_cap) { *a.overflow = 1; a.nsub[blk] = 0; a.ntok[blk] = 0; return; }
             int midx, mlen;
             bool hit = false;
             if (ipos + kSentinel < ilen) {
@@ -196,7 +197,7 @@ void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_dict_reset, dim3(2048), dim3(256), 0, s, dict, nblocks);
 }
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_rolz_parse_serial, dim3(nblocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_rolz_parse_serial, dim3(nblocks - a.blk0), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------ K1 (wavefront form)
@@ -478,13 +479,13 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     __shared__ unsigned long long ektab[256 + 1];
     __shared__ unsigned long long pred_mask;         // lanes that are the in-slot predecessor of a later lane of the same commit set
     __shared__ int pf_pos, pf_level, pf_done;        // round start / level / end flag published for the prefetch wave
-    const uint32_t blk = blockIdx.x;
+    const uint32_t blk = blockIdx.x + a.blk0;
     const size_t base = (size_t)blk * kBlockIn;
     if (base >= a.in_len) return;
     const uint8_t* buf = a.in + base;
     const int ilen = (int)((a.in_len - base) < (size_t)kBlockIn ? (a.in_len - base) : (size_t)kBlockIn);
     uint8_t* dict = a.dict + (size_t)blk * kDictBytes;
-    uint32_t* tok = a.tok + (size_t)blk * kTokCap;
+    uint32_t* tok = a.tok + (size_t)blk * a.tok_cap;
     SubCut* cuts = a.cuts + (size_t)blk * kMaxSub;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -529,11 +530,12 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
 
     uint32_t nt = 0;
     int q = 0, nsub = 0;
+    bool overflow = false;
     unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
     unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0;
     const bool prof = kProf && a.dbg != nullptr;
 
-    while (q < ilen) {                               // ---- one sub-block (one EncodeImpl call)
+    while (q < ilen && !overflow) {                  // ---- one sub-block (one EncodeImpl call)
         const LevelCfg cfg = kAllL0 ? level_cfg(0) : level_cfg(a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)]);
         if (lane == 0) __atomic_store_n(&pf_level, (int)a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)], __ATOMIC_RELAXED);
         const bool level0 = kAllL0 || (cfg.depth == 2 && cfg.lazy1 == 1 && cfg.lazy2 == 0);
@@ -551,6 +553,8 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
         while (q < ilen && opos + 1 < kSubSyms) {    // ---- one round
             // round state is wave-uniform by construction; pin it to scalar registers
             q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
+            // a round adds at most one token per window position; out of token words -> the host grows the pool and repeats
+            if (nt + 64u > a.tok_cap) { overflow = true; break; }
             const int P = q;
             if (lane == 0) __atomic_store_n(&pf_pos, P, __ATOMIC_RELAXED);
             unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -887,15 +891,20 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
         if (nsub < kMaxSub && lane == 0) cuts[nsub] = SubCut{tok_begin, nt, (uint32_t)q, (uint32_t)opos};
         nsub++;
     }
-    if (lane == 0) { __atomic_store_n(&pf_done, 1, __ATOMIC_RELAXED); a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt; }
+    if (lane == 0) {
+        __atomic_store_n(&pf_done, 1, __ATOMIC_RELAXED);
+        if (overflow) { *a.overflow = 1; nsub = 0; nt = 0; }
+        a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt;
+    }
     if (prof && lane == 0) {
-        unsigned long long* d = a.dbg + (size_t)blk * 16;
-        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same; d[15] = c_val; d[11] = c_com;
+        unsigned long long* d = a.dbg + (size_t)blk * kDbgSlots;
+        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same; d[15] = c_val; d[16] = c_com;
     }
 }
 
-void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0) {
+void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks_all, hipStream_t s, bool all_level0) {
     const bool prof = a.dbg != nullptr;
+    const uint32_t nblocks = nblocks_all - a.blk0;
     if (all_level0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wave<true, false>), dim3(nblocks), dim3(64 * (1 + a.pf_waves)), 0, s, a);
     else if (all_level0) hipLaunchKernelGGL((k_rolz_parse_wave<true, true>), dim3(nblocks), dim3(64 * (1 + a.pf_waves)), 0, s, a);
     else if (!prof) hipLaunchKernelGGL((k_rolz_parse_wave<false, false>), dim3(nblocks), dim3(64 * (1 + a.pf_waves)), 0, s, a);

@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -59,7 +60,11 @@ struct zlng_ctx {
     uint64_t* d_blk_end = nullptr;
     uint64_t* d_summary = nullptr;
     uint8_t*  d_mtf = nullptr;        // live MTF tables (65,536 B)
-    uint8_t*  d_mtf_saved = nullptr;  // tables at call entry (restored when a level re-run is needed)
+    uint8_t*  d_mtf_snap = nullptr;   // tables at the start of every rank group of the current call: [0] = call entry (restored
+                                      // when the call fails), [g] = where a level-schedule repair in group g restarts
+    uint32_t  tok_cap = kTokCapDefault;   // token words per block the pools are sized for (grows once to kTokCapMax)
+    bool      tokens_ranked = false;      // the pending parse's literals were already ranked in place by a failed finish
+    int       last_passes = 0;            // parse passes the last encode call needed (1 + level-schedule repairs + pool growth)
     unsigned long long* d_dbg = nullptr;  // parser phase counters (ZLNG_PROFILE=1)
     uint32_t* d_tile_base = nullptr;
     uint32_t* d_tile_hist = nullptr;
@@ -152,33 +157,56 @@ int ensure_out(zlng_ctx* c, size_t bytes) {
     return rc;
 }
 
-void launch_parse(zlng_ctx* c, const ParseArgs& pa, uint32_t nb) {
-    if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
-    else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
-}
+constexpr uint32_t kRankGroup = 8;        // blocks per rank group at levels 1-4 (granularity of a level-schedule repair)
 
-// Parse + rank + histogram + lengths for nb blocks under the current level schedule; repeats
-// with a corrected schedule when the reference's level adaptation (src/libzling.cpp:261-266)
-// would have chosen differently.  At level 0 the schedule is always right (fallback == level).
-int run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, bool rank_now) {
-    static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
-    static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
-    static const int pf_waves = getenv("ZLNG_PF_WAVES") ? std::min(3, std::max(1, atoi(getenv("ZLNG_PF_WAVES")))) : 1;
-    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves};
-    launch_dict_reset(c->d_dict, nb, c->stream);
-    timer_mark(c, "dict_reset");
-    launch_parse(c, pa, nb);
-    timer_mark(c, "rolz_parse");
-    (void)rank_now;
+uint32_t rank_group_blocks(const zlng_ctx* c, uint32_t nb) { return c->level == 0 ? nb : kRankGroup; }
+uint32_t* overflow_flag(zlng_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_summary + 4); }
+
+// (Re)allocate the pools whose size follows the token capacity per block.
+int alloc_token_pools(zlng_ctx* c, uint32_t tok_cap) {
+    for (void* p : {(void*)c->d_tok, (void*)c->d_tile_hist, (void*)c->d_lit_byte}) if (p) hipFree(p);
+    c->d_tok = nullptr; c->d_tile_hist = nullptr; c->d_lit_byte = nullptr;
+    const size_t nb = c->max_blocks;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_tok, nb * tok_cap)) || (rc = dev_alloc(c, &c->d_tile_hist, nb * (tok_cap / 4096) * 256)) ||
+        (rc = dev_alloc(c, &c->d_lit_byte, nb * tok_cap + 256 * 64 + 128)))      // + run alignment + one tile of read-ahead
+        return rc;
+    c->tok_cap = tok_cap;
     return ZLNG_OK;
 }
 
-int run_back(zlng_ctx* c, uint32_t nb, uint8_t* d_out, size_t out_cap) {
-    MtfArgs ma{c->d_tok, c->d_ntok, nb, c->d_mtf, c->d_tile_base, c->d_tile_hist, c->d_ctx_total, c->d_ctx_off, c->d_lit_byte};
-    launch_mtf_rank(ma, c->stream);
+// Reset + parse of blocks [blk0, nb) under the schedule in d_sched.
+void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uint32_t blk0) {
+    static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
+    static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
+    static const int pf_waves = getenv("ZLNG_PF_WAVES") ? std::min(3, std::max(1, atoi(getenv("ZLNG_PF_WAVES")))) : 1;
+    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
+                 c->tok_cap, blk0, overflow_flag(c)};
+    launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream);
+    timer_mark(c, "dict_reset");
+    if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
+    else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
+    timer_mark(c, "rolz_parse");
+}
+
+HuffArgs huff_args(zlng_ctx* c, uint32_t nb, uint32_t blk0, uint8_t* d_out, size_t out_cap) {
+    return HuffArgs{c->d_tok, c->d_cuts, c->d_nsub, nb, c->tok_cap, blk0, c->d_freq, c->d_lens, c->d_codes, c->d_olen,
+                    c->d_sub_off, c->d_blk_end, c->d_summary, overflow_flag(c), d_out, (uint64_t)out_cap};
+}
+
+// Rank (group by group from group g0, whose entry tables are in d_mtf), histogram and lengths of blocks [g0 * G, nb).
+int run_back(zlng_ctx* c, uint32_t nb, uint32_t g0, uint8_t* d_out, size_t out_cap) {
+    const uint32_t G = rank_group_blocks(c, nb);
+    for (uint32_t b = g0 * G, g = g0; b < nb; b += G, g++) {
+        const uint32_t n = std::min(G, nb - b);
+        MtfArgs ma{c->d_tok + (size_t)b * c->tok_cap, c->d_ntok + b, n, c->tok_cap, c->d_mtf, c->d_tile_base, c->d_tile_hist,
+                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte};
+        launch_mtf_rank(ma, c->stream);
+        if (b + G < nb)        // tables at the start of the next group
+            CTX_HIP(hipMemcpyAsync(c->d_mtf_snap + (size_t)(g + 1) * ZLNG_MTF_STATE, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+    }
     timer_mark(c, "mtf_rank");
-    HuffArgs ha{c->d_tok, c->d_cuts, c->d_nsub, nb, c->d_freq, c->d_lens, c->d_codes, c->d_olen,
-                c->d_sub_off, c->d_blk_end, c->d_summary, d_out, (uint64_t)out_cap};
+    const HuffArgs ha = huff_args(c, nb, g0 * G, d_out, out_cap);
     launch_histogram(ha, c->stream);
     timer_mark(c, "histogram");
     launch_lengths(ha, c->stream);
@@ -186,18 +214,33 @@ int run_back(zlng_ctx* c, uint32_t nb, uint8_t* d_out, size_t out_cap) {
     return ZLNG_OK;
 }
 
-// Host check of the level schedule against what the reference would have used.  Returns true
-// if consistent; otherwise rewrites h_sched from the first disagreement on (propagating the
-// corrected level forward as the new speculation).  *final_level gets current_level after the range.
-bool verify_schedule(zlng_ctx* c, uint32_t nb, int entry_level, int* final_level) {
+// Host check of the level schedule against what the reference would have used (src/libzling.cpp:261-266).  Returns true if
+// consistent.  Otherwise *bad_blk names the block of the first disagreement and h_sched is rewritten from there on: the
+// offending sub-block gets the level the reference would have used, and every later one a new speculation derived from the
+// payload ratios measured in this pass (the decision a sub-block's ratio implies is a property of the data around it, so
+// the same pass usually predicts all further flips of the range at once -- the number of passes follows the number of
+// mispredictions, not the number of flips).  *final_level gets current_level after the range.
+bool verify_schedule(zlng_ctx* c, uint32_t nb, int entry_level, int* final_level, uint32_t* bad_blk) {
     int cur = entry_level;
     for (uint32_t b = 0; b < nb; b++) {
         uint32_t old = 0;
         for (uint32_t s = 0; s < c->h_nsub[b] && s < (uint32_t)kMaxSub; s++) {
             const size_t si = (size_t)b * kMaxSub + s;
             if (c->h_sched[si] != (uint8_t)cur) {
-                const size_t total = (size_t)nb * kMaxSub;
-                for (size_t k = si; k < total; k++) c->h_sched[k] = (uint8_t)cur;
+                *bad_blk = b;
+                int guess = cur;
+                for (uint32_t b2 = b; b2 < nb; b2++) {
+                    uint32_t o2 = 0;
+                    for (uint32_t s2 = 0; s2 < (uint32_t)kMaxSub; s2++) {
+                        const size_t k = (size_t)b2 * kMaxSub + s2;
+                        const bool known = s2 < c->h_nsub[b2];
+                        if (b2 > b || s2 >= s) {
+                            c->h_sched[k] = (uint8_t)guess;
+                            if (known) guess = (double)c->h_olen[k] / (double)(c->h_cuts[k].encpos - o2 + 1) > 0.95 ? 0 : c->level;
+                        }
+                        if (known) o2 = c->h_cuts[k].encpos;
+                    }
+                }
                 return false;
             }
             const uint32_t enc = c->h_cuts[si].encpos;
@@ -208,6 +251,13 @@ bool verify_schedule(zlng_ctx* c, uint32_t nb, int entry_level, int* final_level
     }
     *final_level = cur;
     return true;
+}
+
+// A failed call must leave the stream state as it found it (the caller may retry with a larger buffer).
+int fail_restore(zlng_ctx* c, int rc) {
+    hipMemcpyAsync(c->d_mtf, c->d_mtf_snap, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream);
+    hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t* d_out, size_t out_cap,
@@ -222,50 +272,79 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
 
     const int entry_level = c->current_level;
     const size_t nsubs = (size_t)nb * kMaxSub;
-    if (do_parse) {
-        timer_begin(c);
-        for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)(k == 0 ? entry_level : c->level);
-        // the entry level only differs from `level` when the previous range ended incompressible
-        if (entry_level != c->level) for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)entry_level;
-    }
-    CTX_HIP(hipMemcpyAsync(c->d_mtf_saved, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+    const uint32_t G = rank_group_blocks(c, nb);
+    if (c->tokens_ranked) do_parse = true;            // a failed finish ranked the pending tokens in place: parse again
+    CTX_HIP(hipMemcpyAsync(c->d_mtf_snap, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
 
-    int final_level = entry_level;
-    for (int attempt = 0;; attempt++) {
-        if (do_parse || attempt > 0) {
-            CTX_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
-            run_front(c, d_in, in_len, nb, true);
+    c->last_passes = 0;
+    for (bool grown = false;; grown = true) {         // second turn only after a token-pool overflow
+        if (do_parse) {
+            timer_begin(c);
+            // speculation: the requested level everywhere, except that a range entered at level 0 (the previous range ended
+            // incompressible) is assumed to stay there
+            for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)(entry_level != c->level ? entry_level : c->level);
+            CTX_HIP(hipMemsetAsync(overflow_flag(c), 0, 8, c->stream));
         }
-        if (attempt > 0) CTX_HIP(hipMemcpyAsync(c->d_mtf, c->d_mtf_saved, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
-        run_back(c, nb, d_out, out_cap);
-        if (c->level == 0) { final_level = 0; break; }        // level 0: adaptation is inert
-        CTX_HIP(hipMemcpyAsync(c->h_nsub.data(), c->d_nsub, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        CTX_HIP(hipMemcpyAsync(c->h_cuts.data(), c->d_cuts, nsubs * sizeof(SubCut), hipMemcpyDeviceToHost, c->stream));
-        CTX_HIP(hipMemcpyAsync(c->h_olen.data(), c->d_olen, nsubs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        CTX_HIP(hipStreamSynchronize(c->stream));
-        if (verify_schedule(c, nb, entry_level, &final_level)) break;
-        if (attempt > 4 * kMaxSub * (int)nb) return ZLNG_E_DEVICE;   // cannot happen: each pass fixes >= 1 sub-block
+        int final_level = entry_level;
+        uint32_t restart = 0;                          // first block to (re)parse; a multiple of G
+        bool parse_now = do_parse, overflow = false;
+        for (int attempt = 0;; attempt++) {
+            if (parse_now) {
+                CTX_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
+                run_front(c, d_in, in_len, nb, restart);
+                c->last_passes++;
+            }
+            if (attempt > 0)
+                CTX_HIP(hipMemcpyAsync(c->d_mtf, c->d_mtf_snap + (size_t)(restart / G) * ZLNG_MTF_STATE, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+            c->tokens_ranked = true;
+            int rc = run_back(c, nb, restart / G, d_out, out_cap);
+            if (rc != ZLNG_OK) return fail_restore(c, rc);
+            if (c->level == 0) { final_level = 0; break; }        // level 0: adaptation is inert
+            uint32_t of = 0;
+            CTX_HIP(hipMemcpyAsync(&of, overflow_flag(c), 4, hipMemcpyDeviceToHost, c->stream));
+            CTX_HIP(hipMemcpyAsync(c->h_nsub.data(), c->d_nsub, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            CTX_HIP(hipMemcpyAsync(c->h_cuts.data(), c->d_cuts, nsubs * sizeof(SubCut), hipMemcpyDeviceToHost, c->stream));
+            CTX_HIP(hipMemcpyAsync(c->h_olen.data(), c->d_olen, nsubs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            if (hipStreamSynchronize(c->stream) != hipSuccess) return fail_restore(c, ZLNG_E_DEVICE);
+            if (of) { overflow = true; break; }
+            uint32_t bad = 0;
+            if (verify_schedule(c, nb, entry_level, &final_level, &bad)) break;
+            if (attempt > 4 * kMaxSub * (int)nb) return fail_restore(c, ZLNG_E_DEVICE);   // cannot happen: each pass fixes >= 1 sub-block
+            restart = bad / G * G;
+            parse_now = true;
+        }
+
+        uint64_t summary[2] = {0, 0};
+        if (!overflow) {
+            const HuffArgs ha = huff_args(c, nb, 0, d_out, out_cap);
+            launch_layout(ha, c->stream);
+            timer_mark(c, "layout_scan");
+            launch_pack(ha, c->stream);
+            timer_mark(c, "huff_pack");
+            hipMemcpyAsync(summary, c->d_summary, sizeof summary, hipMemcpyDeviceToHost, c->stream);
+            hipMemcpyAsync(c->h_blk_end.data(), c->d_blk_end, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail_restore(c, ZLNG_E_DEVICE);
+            overflow = (summary[1] & 8) != 0;
+        }
+        if (overflow) {
+            // some block ran out of token words: size the pools for the worst case (one token per byte) and repeat the call
+            if (grown || c->tok_cap >= kTokCapMax) return fail_restore(c, ZLNG_E_DEVICE);
+            hipMemcpyAsync(c->d_mtf, c->d_mtf_snap, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream);
+            hipStreamSynchronize(c->stream);
+            const int rc = alloc_token_pools(c, kTokCapMax);
+            if (rc != ZLNG_OK) return rc;
+            do_parse = true;
+            continue;
+        }
+        if (summary[1] & 2) return fail_restore(c, ZLNG_E_DEVICE);
+        if (summary[1] & 1) return fail_restore(c, ZLNG_E_PAYLOAD);
+        if (summary[1] & 4) return fail_restore(c, ZLNG_E_CAP);
+        *out_len = (size_t)summary[0];
+        if (per_block_out_end) for (uint32_t b = 0; b < nb; b++) per_block_out_end[b] = (size_t)c->h_blk_end[b];
+        c->current_level = final_level;
+        c->tokens_ranked = false;
+        return ZLNG_OK;
     }
-
-    HuffArgs ha{c->d_tok, c->d_cuts, c->d_nsub, nb, c->d_freq, c->d_lens, c->d_codes, c->d_olen,
-                c->d_sub_off, c->d_blk_end, c->d_summary, d_out, (uint64_t)out_cap};
-    launch_layout(ha, c->stream);
-    timer_mark(c, "layout_scan");
-    launch_pack(ha, c->stream);
-    timer_mark(c, "huff_pack");
-
-    uint64_t summary[2] = {0, 0};
-    CTX_HIP(hipMemcpyAsync(summary, c->d_summary, sizeof summary, hipMemcpyDeviceToHost, c->stream));
-    CTX_HIP(hipMemcpyAsync(c->h_blk_end.data(), c->d_blk_end, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    CTX_HIP(hipStreamSynchronize(c->stream));
-    CTX_HIP(hipGetLastError());
-    if (summary[1] & 2) return ZLNG_E_DEVICE;
-    if (summary[1] & 1) return ZLNG_E_PAYLOAD;
-    if (summary[1] & 4) return ZLNG_E_CAP;
-    *out_len = (size_t)summary[0];
-    if (per_block_out_end) for (uint32_t b = 0; b < nb; b++) per_block_out_end[b] = (size_t)c->h_blk_end[b];
-    c->current_level = final_level;
-    return ZLNG_OK;
 }
 
 }  // namespace
@@ -311,26 +390,30 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(ZLNG_E_DEVICE);
     for (int i = 0; i <= kMaxStages; i++) if (hipEventCreate(&c->timer.ev[i]) != hipSuccess) return fail(ZLNG_E_DEVICE);
     const size_t nb = (size_t)max_blocks, nsubs = nb * kMaxSub;
-    if ((rc = dev_alloc(c, &c->d_mtf, ZLNG_MTF_STATE)) || (rc = dev_alloc(c, &c->d_mtf_saved, ZLNG_MTF_STATE))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->d_mtf, ZLNG_MTF_STATE)) ||
+        (rc = dev_alloc(c, &c->d_mtf_snap, ((size_t)max_blocks / kRankGroup + 2) * ZLNG_MTF_STATE))) return fail(rc);
     if (!c->is_encode) {
         const size_t max_subs = nb * kDecSubsPerBlock;
         if ((rc = dev_alloc(c, &c->d_subs, max_subs)) || (rc = dev_alloc(c, &c->d_blocks, nb)) ||
             (rc = dev_alloc(c, &c->d_sub_ntok, max_subs)) || (rc = dev_alloc(c, &c->d_ring, (size_t)256 * kRing)) ||
-            (rc = dev_alloc(c, &c->d_tok, nb * (kTokCap + 64))) || (rc = dev_alloc(c, &c->d_summary, 8)))
+            (rc = dev_alloc(c, &c->d_tok, nb * ((size_t)kTokCapMax + 64))) || (rc = dev_alloc(c, &c->d_summary, 8)))
             return fail(rc);
         c->h_blocks.resize(nb);
     }
     if (c->is_encode) {
-        if ((rc = dev_alloc(c, &c->d_dict, nb * kDictBytes)) || (rc = dev_alloc(c, &c->d_tok, nb * kTokCap)) ||
+        const char* tc = getenv("ZLNG_TOK_CAP");      // token words per block the pools start with (testing aid; multiple of 4096)
+        uint32_t tok_cap = tc ? (uint32_t)strtoul(tc, nullptr, 10) : kTokCapDefault;
+        tok_cap = std::min(kTokCapMax, std::max(8192u, tok_cap / 4096u * 4096u));
+        if ((rc = dev_alloc(c, &c->d_dict, nb * kDictBytes)) || (rc = alloc_token_pools(c, tok_cap)) ||
             (rc = dev_alloc(c, &c->d_cuts, nsubs)) || (rc = dev_alloc(c, &c->d_nsub, nb)) ||
             (rc = dev_alloc(c, &c->d_ntok, nb)) || (rc = dev_alloc(c, &c->d_sched, nsubs)) ||
             (rc = dev_alloc(c, &c->d_freq, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_lens, nsubs * kNsymAll)) ||
             (rc = dev_alloc(c, &c->d_codes, nsubs * kNsymAll)) || (rc = dev_alloc(c, &c->d_olen, nsubs)) ||
             (rc = dev_alloc(c, &c->d_sub_off, nsubs)) || (rc = dev_alloc(c, &c->d_blk_end, nb)) ||
             (rc = dev_alloc(c, &c->d_summary, 8)) || (rc = dev_alloc(c, &c->d_tile_base, nb + 1)) ||
-            (rc = dev_alloc(c, &c->d_tile_hist, nb * (kTokCap / 4096) * 256)) || (rc = dev_alloc(c, &c->d_ctx_total, 256)) ||
-            (rc = dev_alloc(c, &c->d_ctx_off, 256)) || (rc = dev_alloc(c, &c->d_lit_byte, nb * kTokCap + 256 * 64 + 128)))   // + run alignment + one tile of read-ahead
+            (rc = dev_alloc(c, &c->d_ctx_total, 256)) || (rc = dev_alloc(c, &c->d_ctx_off, 256)))
             return fail(rc);
+        if (hipMemset(c->d_summary, 0, 8 * sizeof(uint64_t)) != hipSuccess) return fail(ZLNG_E_DEVICE);
         c->h_sched.resize(nsubs);
         c->h_nsub.resize(nb);
         c->h_olen.resize(nsubs);
@@ -338,8 +421,8 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
         c->h_blk_end.resize(nb);
         const char* pf = getenv("ZLNG_PROFILE");
         if (pf && pf[0] == '1') {
-            if ((rc = dev_alloc(c, &c->d_dbg, nb * 16))) return fail(rc);
-            if (hipMemset(c->d_dbg, 0, nb * 16 * sizeof(unsigned long long)) != hipSuccess) return fail(ZLNG_E_DEVICE);
+            if ((rc = dev_alloc(c, &c->d_dbg, nb * kDbgSlots))) return fail(rc);
+            if (hipMemset(c->d_dbg, 0, nb * kDbgSlots * sizeof(unsigned long long)) != hipSuccess) return fail(ZLNG_E_DEVICE);
         }
     }
     uint8_t init[ZLNG_MTF_STATE];
@@ -353,7 +436,7 @@ void zlng_destroy(zlng_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
-                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_saved, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring, c->d_tile_base, c->d_tile_hist,
+                    c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_snap, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring, c->d_tile_base, c->d_tile_hist,
                     c->d_ctx_total, c->d_ctx_off, c->d_lit_byte};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
@@ -362,11 +445,11 @@ void zlng_destroy(zlng_ctx* c) {
 }
 
 size_t zlng_encode_bound(size_t n) {
-    // every u16 entry covers >= 1 input byte and costs <= 2 payload bytes; every sub-block but the
-    // last of a block has >= 262143 entries
+    // every u16 entry covers >= 1 input byte, every sub-block but the last of a block has >= 262143 entries, and a
+    // payload above 393,216 B is refused (ZLNG_E_PAYLOAD): <= 1.5 output bytes per input byte plus headers
     const size_t nblk = (n + kBlockIn - 1) / kBlockIn;
     const size_t nsub = n / 262143 + nblk + 1;
-    return nsub * (kHeaderBytes + kTableBytes + 8) + 2 * n + nblk + 64;
+    return std::min(nsub * (size_t)(kHeaderBytes + kPayloadMax), 2 * n + nsub * (size_t)(kHeaderBytes + kTableBytes + 8)) + nblk + 64;
 }
 
 int zlng_encode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, void* d_out, size_t out_cap,
@@ -389,9 +472,9 @@ int zlng_encode_blocks(zlng_ctx* c, const uint8_t* in, size_t in_len, uint8_t* o
     CTX_HIP(hipMemcpyAsync(c->d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
     CTX_HIP(hipMemsetAsync(c->d_in + in_len, 0, 512, c->stream));
     size_t produced = 0;
-    rc = encode_device_impl(c, c->d_in, in_len, c->d_out, bound, &produced, per_block_out_end, true);
+    // the caller's capacity is checked on the device before anything is written or the stream state moves on
+    rc = encode_device_impl(c, c->d_in, in_len, c->d_out, std::min(bound, out_cap), &produced, per_block_out_end, true);
     if (rc != ZLNG_OK) return rc;
-    if (produced > out_cap) return ZLNG_E_CAP;
     CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
     *out_len = produced;
@@ -408,7 +491,9 @@ int zlng_encode_parse_device(zlng_ctx* c, const void* d_in, size_t in_len) {
     // speculate the requested level everywhere; finish() re-parses if the incoming level disagrees
     for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)c->level;
     CTX_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
-    run_front(c, static_cast<const uint8_t*>(d_in), in_len, nb, false);
+    CTX_HIP(hipMemsetAsync(overflow_flag(c), 0, 8, c->stream));
+    run_front(c, static_cast<const uint8_t*>(d_in), in_len, nb, 0);
+    c->tokens_ranked = false;
     c->pending_in = static_cast<const uint8_t*>(d_in);
     c->pending_len = in_len;
     c->pending_blocks = nb;
@@ -417,12 +502,11 @@ int zlng_encode_parse_device(zlng_ctx* c, const void* d_in, size_t in_len) {
 
 int zlng_encode_finish_device(zlng_ctx* c, void* d_out, size_t out_cap, size_t* out_len, size_t* per_block_out_end) {
     if (!c || !c->pending_in) return ZLNG_E_ARG;
-    const uint8_t* in = c->pending_in;
-    const size_t n = c->pending_len;
-    c->pending_in = nullptr;
     // a parse speculated at `level` is reusable iff the stream enters this range at `level`
     const bool reuse = (c->current_level == c->level);
-    return encode_device_impl(c, in, n, static_cast<uint8_t*>(d_out), out_cap, out_len, per_block_out_end, !reuse);
+    const int rc = encode_device_impl(c, c->pending_in, c->pending_len, static_cast<uint8_t*>(d_out), out_cap, out_len, per_block_out_end, !reuse);
+    if (rc == ZLNG_OK) c->pending_in = nullptr;       // a failed finish keeps the range pending: it can be repeated (e.g. with more room)
+    return rc;
 }
 
 int zlng_encode_parse(zlng_ctx* c, const uint8_t* in, size_t in_len) {
@@ -439,9 +523,8 @@ int zlng_encode_finish(zlng_ctx* c, uint8_t* out, size_t out_cap, size_t* out_le
     if (!c || !c->pending_in || !out || !out_len) return ZLNG_E_ARG;
     *out_len = 0;
     size_t produced = 0;
-    const int rc = zlng_encode_finish_device(c, c->d_out, zlng_encode_bound(c->pending_len), &produced, per_block_out_end);
+    const int rc = zlng_encode_finish_device(c, c->d_out, std::min(zlng_encode_bound(c->pending_len), out_cap), &produced, per_block_out_end);
     if (rc != ZLNG_OK) return rc;
-    if (produced > out_cap) return ZLNG_E_CAP;
     CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
     *out_len = produced;
@@ -458,7 +541,8 @@ int zlng_get_state(zlng_ctx* c, uint8_t mtf[ZLNG_MTF_STATE], int* current_level)
 }
 
 int zlng_set_state(zlng_ctx* c, const uint8_t mtf[ZLNG_MTF_STATE], int current_level) {
-    if (!c || !mtf || current_level < 0 || current_level > 4) return ZLNG_E_ARG;
+    // current_level is either 0 or the stream's level (src/libzling.cpp:261-266)
+    if (!c || !mtf || (current_level != 0 && current_level != c->level)) return ZLNG_E_ARG;
     for (int ctx = 0; ctx < 256; ctx++) {           // every table must be a permutation of 0..255
         bool seen[256] = {false};
         for (int i = 0; i < 256; i++) { uint8_t v = mtf[256 * ctx + i]; if (seen[v]) return ZLNG_E_ARG; seen[v] = true; }
@@ -480,7 +564,7 @@ int zlng_get_state_device(zlng_ctx* c, void* d_mtf, int* current_level) {
 }
 
 int zlng_set_state_device(zlng_ctx* c, const void* d_mtf, int current_level) {
-    if (!c || !d_mtf || current_level < 0 || current_level > 4) return ZLNG_E_ARG;
+    if (!c || !d_mtf || (current_level != 0 && current_level != c->level)) return ZLNG_E_ARG;
     CTX_HIP(hipSetDevice(c->device));
     CTX_HIP(hipMemcpyAsync(c->d_mtf, d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
@@ -502,7 +586,7 @@ int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size
     CTX_HIP(hipSetDevice(c->device));
     timer_begin(c);
     DecodeArgs da{static_cast<const uint8_t*>(d_in), (uint64_t)in_len, c->max_blocks, c->max_blocks * kDecSubsPerBlock,
-                  (uint64_t)c->max_blocks * (kTokCap + 64), c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_tok, c->d_ring,
+                  (uint64_t)c->max_blocks * ((uint64_t)kTokCapMax + 64), c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_tok, c->d_ring,
                   c->d_mtf, static_cast<uint8_t*>(d_out), (uint64_t)out_cap, c->d_summary};
     launch_frame_walk(da, c->stream);
     timer_mark(c, "frame_walk");
@@ -567,7 +651,7 @@ int zlng_last_timings(zlng_ctx* c, const char** names, float* ms, int cap) {
 // stage-level parity tests can compare each kernel with the oracle's stage API.
 //   what: 0 tokens (u32 x ntok), 1 cuts (SubCut x nsub), 2 freq (u32 x 546 per sub-block, kMaxSub rows),
 //         3 lens (u8 x 546 rows), 4 olen (u32 x kMaxSub), 5 ntok/nsub (2 x u32), 6 codes (u16 x 546 rows),
-//         7 sub-block output offsets (u64 x kMaxSub)
+//         7 sub-block output offsets (u64 x kMaxSub), 8 literals per context of the last rank group (u32 x 256; blk ignored)
 int zlng_debug_fetch(zlng_ctx* c, int what, int blk, void* dst, size_t bytes) {
     if (!c || !c->is_encode || blk < 0 || (uint32_t)blk >= c->max_blocks || !dst) return ZLNG_E_ARG;
     CTX_HIP(hipSetDevice(c->device));
@@ -576,13 +660,14 @@ int zlng_debug_fetch(zlng_ctx* c, int what, int blk, void* dst, size_t bytes) {
     size_t cap = 0;
     uint32_t two[2];
     switch (what) {
-        case 0: src = c->d_tok + (size_t)blk * kTokCap; cap = kTokCap * 4; break;
+        case 0: src = c->d_tok + (size_t)blk * c->tok_cap; cap = (size_t)c->tok_cap * 4; break;
         case 1: src = c->d_cuts + (size_t)blk * kMaxSub; cap = sizeof(SubCut) * kMaxSub; break;
         case 2: src = c->d_freq + (size_t)blk * kMaxSub * kNsymAll; cap = (size_t)kMaxSub * kNsymAll * 4; break;
         case 3: src = c->d_lens + (size_t)blk * kMaxSub * kNsymAll; cap = (size_t)kMaxSub * kNsymAll; break;
         case 4: src = c->d_olen + (size_t)blk * kMaxSub; cap = (size_t)kMaxSub * 4; break;
         case 6: src = c->d_codes + (size_t)blk * kMaxSub * kNsymAll; cap = (size_t)kMaxSub * kNsymAll * 2; break;
         case 7: src = c->d_sub_off + (size_t)blk * kMaxSub; cap = (size_t)kMaxSub * 8; break;
+        case 8: src = c->d_ctx_total; cap = 256 * 4; break;
         case 5:
             CTX_HIP(hipMemcpy(&two[0], c->d_ntok + blk, 4, hipMemcpyDeviceToHost));
             CTX_HIP(hipMemcpy(&two[1], c->d_nsub + blk, 4, hipMemcpyDeviceToHost));
@@ -596,10 +681,31 @@ int zlng_debug_fetch(zlng_ctx* c, int what, int blk, void* dst, size_t bytes) {
     return ZLNG_OK;
 }
 
+// Test hook: run K4 (code lengths + canonical codes) on caller-supplied frequency rows (546 counts each: 514 of alphabet 1,
+// 32 of alphabet 2), so the tie-heavy golden tables of the reference reach the device heap directly.
+int zlng_debug_lengths(zlng_ctx* c, const uint32_t* freq, int nrows, uint8_t* lens, uint16_t* codes) {
+    if (!c || !c->is_encode || !freq || !lens || nrows <= 0 || (size_t)nrows > (size_t)c->max_blocks * kMaxSub) return ZLNG_E_ARG;
+    CTX_HIP(hipSetDevice(c->device));
+    const uint32_t nb = ((uint32_t)nrows + kMaxSub - 1) / kMaxSub;
+    std::vector<uint32_t> nsub(nb);
+    for (uint32_t b = 0; b < nb; b++) nsub[b] = std::min<uint32_t>(kMaxSub, (uint32_t)nrows - b * kMaxSub);
+    CTX_HIP(hipMemcpyAsync(c->d_nsub, nsub.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    CTX_HIP(hipMemcpyAsync(c->d_freq, freq, (size_t)nrows * kNsymAll * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    launch_lengths(huff_args(c, nb, 0, nullptr, 0), c->stream);
+    CTX_HIP(hipMemcpyAsync(lens, c->d_lens, (size_t)nrows * kNsymAll, hipMemcpyDeviceToHost, c->stream));
+    if (codes) CTX_HIP(hipMemcpyAsync(codes, c->d_codes, (size_t)nrows * kNsymAll * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    CTX_HIP(hipGetLastError());
+    return ZLNG_OK;
+}
+
+// Test hook: parse passes of the last encode call (1 = the speculated level schedule was right and the pools sufficed).
+int zlng_debug_passes(zlng_ctx* c) { return c ? c->last_passes : -1; }
+
 // Undocumented profiling aid (ZLNG_PROFILE=1): copies 16 counters per block of the last parse.
 int zlng_debug_counters(zlng_ctx* c, unsigned long long* out, int nblocks) {
     if (!c || !c->d_dbg || nblocks > (int)c->max_blocks) return ZLNG_E_ARG;
-    CTX_HIP(hipMemcpy(out, c->d_dbg, (size_t)nblocks * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    CTX_HIP(hipMemcpy(out, c->d_dbg, (size_t)nblocks * kDbgSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return ZLNG_OK;
 }
 

@@ -41,7 +41,13 @@ constexpr size_t   kDictBytes    = (size_t)256 * kBktBytes;                  // 
 //  bits 0..15  alphabet-1 symbol (raw byte before the rank stage, rank after it)
 //  bits 16..31 match: match_idx | literal: context byte, 0xFFFF for the 2 raw block-opening bytes
 constexpr uint32_t kTokRawCtx = 0xFFFFu;
-constexpr size_t   kTokCap    = (size_t)kBlockIn;           // token words reserved per block
+// Token words reserved per block (`tok_cap` in the kernel argument blocks) are a property of the context: text needs
+// 0.25-0.29 tokens per byte, incompressible data one per byte.  A context starts at kTokCapDefault and, when a parse
+// reports an overflow, grows once to the worst case kTokCapMax and repeats the call (zlng_api.hip).  Multiples of 4096
+// (one partition tile of the rank stage).
+constexpr uint32_t kTokCapMax     = (uint32_t)kBlockIn;          // one token per input byte
+constexpr uint32_t kTokCapDefault = 7u << 20;                    // 0.4375 tokens per byte
+constexpr uint32_t kDbgSlots      = 24;                          // parser profile counters per block (ZLNG_PROFILE=1)
 
 struct SubCut {            // one sub-block of one block
     uint32_t tok_begin;    // first token (index into the block's token array)

@@ -9,25 +9,30 @@ struct ParseArgs {
     const uint8_t* in;        // NB x 16 MiB contiguous input (readable for in_len + 512)
     size_t         in_len;
     uint8_t*       dict;      // NB x kDictBytes
-    uint32_t*      tok;       // NB x kTokCap token words (literals RAW on exit)
+    uint32_t*      tok;       // NB x tok_cap token words (literals RAW on exit)
     SubCut*        cuts;      // NB x kMaxSub
     uint32_t*      nsub;      // NB
     uint32_t*      ntok;      // NB
     const uint8_t* lvl_sched; // NB x kMaxSub: level of each sub-block (src/libzling.cpp:261-266 speculation)
-    unsigned long long* dbg;  // optional NB x 16 counters (cycles per phase, rounds, redos); may be null
+    unsigned long long* dbg;  // optional NB x kDbgSlots counters (cycles per phase, rounds, redos); may be null
     int            min_restart; // a conflict at lane >= this restarts the round there instead of replaying the token
     int            pf_ahead;    // how many positions past its lead the far prefetch wavefront may run (tuning)
     int            pf_waves;    // prefetch wavefronts per block (1..3)
+    uint32_t       tok_cap;     // token words reserved per block
+    uint32_t       blk0;        // first block of this launch (a level-schedule repair re-parses a tail of the range)
+    uint32_t*      overflow;    // set to 1 by a block that ran out of token words (its output is then incomplete)
 };
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s);
+// both parse blocks [a.blk0, nblocks)
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
 void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);
 
 // ---- K2 ------------------------------------------------------------------------------
 struct MtfArgs {
-    uint32_t*       tok;       // NB x kTokCap, ranked in place
+    uint32_t*       tok;       // NB x tok_cap, ranked in place (pointer to the first block of the group being ranked)
     const uint32_t* ntok;      // NB
     uint32_t        nblocks;
+    uint32_t        tok_cap;
     uint8_t*        state;     // 256 x 256 MTF tables, context-major; updated in place
     uint32_t*       tile_base; // [NB + 1] dense tile number of each block's first tile
     uint32_t*       tile_hist; // [tiles][256] literals per context per tile -> exclusive prefix per context
@@ -43,13 +48,16 @@ struct HuffArgs {
     const SubCut*   cuts;
     const uint32_t* nsub;
     uint32_t        nblocks;
+    uint32_t        tok_cap;
+    uint32_t        blk0;      // histogram / lengths only: first block to (re)compute
     uint32_t*       freq;      // [NB*kMaxSub][kNsymAll]
     uint8_t*        lens;      // [NB*kMaxSub][kNsymAll]
     uint16_t*       codes;     // [NB*kMaxSub][kNsymAll] (bit-reversed canonical codes)
     uint32_t*       olen;      // [NB*kMaxSub] payload bytes (273 + bitstream)
     uint64_t*       sub_off;   // [NB*kMaxSub] byte offset of the sub-block's 0x01 flag in the output
     uint64_t*       blk_end;   // [NB] end offset of each block's bytes
-    uint64_t*       summary;   // [0] total bytes, [1] error flag (ZLNG_E_PAYLOAD as positive), [2] scratch
+    uint64_t*       summary;   // [0] total bytes, [1] error flags: 1 payload > 393,216 B, 2 internal, 4 out_cap, 8 token-pool overflow
+    const uint32_t* overflow;  // set by the parser when a block ran out of token words
     uint8_t*        out;
     uint64_t        out_cap;
 };

@@ -79,6 +79,22 @@ int pick_device() {
     const char* e = getenv("ZLNG_DEVICE");
     return e ? atoi(e) : 0;
 }
+// Devices an Encode() call spreads one stream over: ZLNG_DEVICES="0,1,2,3" (an index may repeat: several contexts on
+// one GPU), else the single device of ZLNG_DEVICE, else device 0.
+std::vector<int> pick_devices() {
+    std::vector<int> d;
+    if (const char* e = getenv("ZLNG_DEVICES")) {
+        for (const char* p = e; *p;) {
+            char* end = nullptr;
+            long v = strtol(p, &end, 10);
+            if (end == p) break;
+            d.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (d.empty()) d.push_back(pick_device());
+    return d;
+}
 
 struct CtxGuard {
     zlng_ctx* c;
@@ -112,13 +128,23 @@ struct RawBuf {
 };
 
 struct EncodeSlot {
-    zlng_ctx* ctx = nullptr;
+    zlng_group* grp = nullptr;    // one context per device of ZLNG_DEVICES; a batch is split into contiguous block ranges
     RawBuf in, out;
     std::vector<size_t> ilen, ends;
     int have = 0;                 // blocks read into `in`
     size_t total = 0;             // their bytes
-    ~EncodeSlot() { if (ctx) zlng_destroy(ctx); }
+    ~EncodeSlot() { if (grp) zlng_group_destroy(grp); }
 };
+
+zlng_group* make_group(const std::vector<int>& devices, int level, int blocks_per_member) {
+    int err = 0;
+    zlng_group* g = zlng_group_create(devices.data(), (int)devices.size(), level, blocks_per_member, &err);
+    if (!g) {
+        if (err == ZLNG_E_NOMEM) throw std::bad_alloc();
+        throw std::runtime_error(std::string("zling: no gfx950 device (") + zlng_strerror(err) + ")");
+    }
+    return g;
+}
 
 void throw_rc(int rc) {
     if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
@@ -160,7 +186,10 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
     }
     bool bad_level = level < 0 || level > 4;     // the reference would emit a corrupt stream
     if (!bad_level) {
-        const int nb = batch_blocks();
+        const std::vector<int> devices = pick_devices();
+        const int ndev = (int)devices.size();
+        const int per_member = std::max(1, batch_blocks());
+        const int nb = per_member * ndev;                 // blocks per batch: every device gets `per_member` of them
         const char* pe = getenv("ZLNG_PIPELINE");
         const bool pipelined = !(pe && atoi(pe) == 0);
         const int nslots = pipelined ? 2 : 1;
@@ -175,17 +204,17 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
             s.ends.resize((size_t)nb);
         };
         auto prepare_ctx = [&](EncodeSlot& s, bool stream_ended) {
-            if (!s.ctx) s.ctx = make_ctx(level, true, stream_ended ? std::max(s.have, 1) : nb);
+            if (!s.grp) s.grp = make_group(devices, level, stream_ended ? std::max((s.have + ndev - 1) / ndev, 1) : per_member);
         };
         std::vector<unsigned char> state(ZLNG_MTF_STATE);
         int state_level = level;
         bool have_state = false, failed = false;
         // GPU half of a batch (any thread; touches only its slot and the state hand-off, never the streams)
         auto gpu_finish = [&](EncodeSlot* s) {
-            if (have_state) throw_rc(zlng_set_state(s->ctx, state.data(), state_level));
+            if (have_state) throw_rc(zlng_group_set_state(s->grp, state.data(), state_level));
             size_t produced = 0;
-            throw_rc(zlng_encode_finish(s->ctx, s->out.data(), s->out.size(), &produced, s->ends.data()));
-            throw_rc(zlng_get_state(s->ctx, state.data(), &state_level));
+            throw_rc(zlng_group_encode_finish(s->grp, s->out.data(), s->out.size(), &produced, s->ends.data()));
+            throw_rc(zlng_group_get_state(s->grp, state.data(), &state_level));
             have_state = true;
         };
         // bytes, then the callback, block by block (src/libzling.cpp:273-283); caller's thread
@@ -210,7 +239,7 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
             if (!read_batch(inputter, cur, nb)) { failed = true; break; }
             if (cur.have == 0) break;
             prepare_ctx(cur, cur.have < nb || inputter->IsEnd());
-            throw_rc(zlng_encode_parse(cur.ctx, cur.in.data(), cur.total));
+            throw_rc(zlng_group_encode_parse(cur.grp, cur.in.data(), cur.total));
             EncodeSlot* done = pending_slot;
             if (pending.valid()) pending.get();                      // batch k-1 is back (rethrows its error)
             if (pipelined) {

@@ -42,6 +42,8 @@ class Oracle:
         L.zo_reset_buckets.argtypes = [C.c_void_p]
         L.zo_stream_get_mtf.argtypes = [C.c_void_p, _u8p]
         L.zo_stream_set_mtf.argtypes = [C.c_void_p, _u8p]
+        L.zo_stream_get_level.argtypes = [C.c_void_p]
+        L.zo_stream_set_level.argtypes = [C.c_void_p, C.c_int]
         L.zo_encode_blocks.argtypes = [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.zo_parse_subblock.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_int), C.c_void_p,
                                         C.POINTER(C.c_int), C.c_int]
@@ -150,6 +152,8 @@ class Reference:
         L.ref_rolz_new.restype = C.c_void_p
         L.ref_rolz_free.argtypes = [C.c_void_p]
         L.ref_rolz_block.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.ref_mtf_chain.argtypes = [_u8p, C.c_size_t, _u8p]
+        L.ref_mtf_chain.restype = C.c_uint64
 
     def encode(self, data, level=0):
         a = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
@@ -174,6 +178,13 @@ class Reference:
         out = np.zeros(freq.size + (freq.size & 1), np.uint32)
         self.lib.ref_make_length_table(freq.ctypes.data, out.ctypes.data, freq.size, limit)
         return out[: freq.size]
+
+    def mtf_chain(self, lits):
+        """Ranks of one context's literal bytes from the initial table (the reference's ZlingMTFEncoder)."""
+        a = np.ascontiguousarray(lits, dtype=np.uint8)
+        out = np.empty(a.size, np.uint8)
+        self.lib.ref_mtf_chain(_ptr(a), a.size, _ptr(out))
+        return out
 
     def rolz_block(self, block, level=0):
         """Reference u16 token stream of one block with a FRESH encoder: (tok16, [(encpos, rlen)])."""

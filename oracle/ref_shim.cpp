@@ -93,4 +93,13 @@ int ref_rolz_block(void* e, int level, uint8_t* ibuf, int ilen, uint16_t* tok16,
     return nsub;
 }
 
+// Stage probe for bench.py's `rank_chain` line: the reference's own MTF encoder (src/libzling_lz.cpp:106-117) over the
+// literal bytes of ONE context, from the initial table.  Returns a checksum of the ranks so the loop cannot be elided.
+uint64_t ref_mtf_chain(const uint8_t* lits, size_t n, uint8_t* ranks) {
+    baidu::zling::lz::ZlingMTFEncoder m;
+    uint64_t sum = 0;
+    for (size_t i = 0; i < n; i++) { const unsigned char r = m.Encode(lits[i]); if (ranks) ranks[i] = r; sum += r; }
+    return sum;
+}
+
 }  // extern "C"

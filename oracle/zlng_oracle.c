@@ -109,6 +109,9 @@ zo_stream* zo_stream_new(int level) {
 }
 void zo_stream_free(zo_stream* s) { free(s); }
 
+/* current_level (src/libzling.cpp:185): part of the stream state a block-range hand-off carries */
+int  zo_stream_get_level(const zo_stream* s) { return s->current_level; }
+void zo_stream_set_level(zo_stream* s, int level) { s->current_level = level; }
 void zo_stream_get_mtf(const zo_stream* s, uint8_t t[256 * 256]) {
     for (int c = 0; c < 256; c++) memcpy(t + 256 * c, s->mtf[c].table, 256);
 }

@@ -71,3 +71,22 @@ ALL = {**SMALL, **LARGE}
 
 def get(name):
     return np.ascontiguousarray(ALL[name](), dtype=np.uint8)
+
+
+def corrupt_cases(oracle):
+    """Deterministic streams that hit each Huffman validity check of the decoder exactly (src/libzling.cpp:381, 391, 398):
+    [(name, bytes, oracle error code)].  Built from the one-sub-block stream of text_64k:
+      * code1  -- all 257 nibble bytes of length table 1 zeroed: no code exists, the first 15-bit lookup misses;
+      * code2  -- the 16 nibble bytes of length table 2 zeroed: the first match's index code misses;
+      * exbits -- rlen cut so that the last u16 entry is a match symbol whose index entry falls outside the sub-block."""
+    x = get("text_64k")
+    z = oracle.encode(x, 0)
+    pay = 13                                           # flag + encpos + rlen + olen
+    c1 = z.copy(); c1[pay:pay + 257] = 0
+    c2 = z.copy(); c2[pay + 257:pay + 273] = 0
+    tok, _ = oracle.parse_block(x, 0)
+    first_match = int(np.argmax((tok & 0xFFFF) >= 258))
+    assert (tok[first_match] & 0xFFFF) >= 258 and not ((tok[:first_match] & 0xFFFF) >= 258).any()
+    ex = z.copy()
+    ex[5:9] = list(int(first_match + 1).to_bytes(4, "big"))       # u16 index of the first match == its token index
+    return x, [("code1", c1, -4), ("code2", c2, -5), ("exbits", ex, -6)]

@@ -118,3 +118,19 @@ def test_split_host_api_matches_one_call(oracle):
             parts.append(out[:n.value].copy())
             st = ctxs[i].get_state()
     assert np.array_equal(np.concatenate(parts), want)
+
+
+@pytest.mark.parametrize("level,devices,batch", [(0, "0,0", 2), (4, "0,0", 1), (4, "0,0,0", 2)])
+def test_shim_spreads_one_stream_over_devices(oracle, level, devices, batch):
+    """ZLNG_DEVICES: baidu::zling::Encode hands every batch to a zlng_group -- one context per listed device, contiguous
+    block ranges, MTF tables + current_level handed member to member (src/libzling.cpp:185, 197, 261-266).  Two or three
+    contexts on device 0 stand in for as many GPUs; the incompressible stretch crosses member and batch boundaries."""
+    import libzling_amd as zl
+    from oracle_py import textgen
+    rng = np.random.default_rng(78)
+    x = np.concatenate([textgen(2 * zl.BLOCK - 400_000, 7), rng.integers(0, 256, 900_000, dtype=np.uint8),
+                        textgen(3 * zl.BLOCK + 55_555, 8)])
+    want = oracle.encode(x, level)
+    env = dict(os.environ, ZLNG_DEVICES=devices, ZLNG_BATCH_BLOCKS=str(batch))
+    p = subprocess.run([DEMO, "e%d" % level], input=x.tobytes(), stdout=subprocess.PIPE, check=True, env=env)
+    assert np.array_equal(np.frombuffer(p.stdout, dtype=np.uint8), want)

@@ -80,3 +80,28 @@ def test_corrupt_streams_map_to_reference_errors(zl, oracle):
             assert back.size <= x.size
         except zl.ZlngError as e:
             assert e.code in (-12, -13, -14, -15, -1)
+
+
+def test_each_huffman_validity_check_deterministically(zl, oracle):
+    x, cases = corpus.corrupt_cases(oracle)
+    want_gpu = {"code1": -12, "code2": -13, "exbits": -14}
+    for name, bad, ocode in cases:
+        assert oracle.decode(bad, x.size)[0] == ocode, name
+        with pytest.raises(zl.ZlngError) as e:
+            gpu_decode(zl, bad, x.size)
+        assert e.value.code == want_gpu[name], (name, e.value.code)
+
+
+def test_full_size_decode_round_trip(zl):
+    """BASELINE config 5: the e0 .zlng of the 10^9-byte stream decodes back to the input (SHA-256), 60 blocks in one call."""
+    import hashlib
+    from oracle_py import textgen
+    n = 1_000_000_000
+    x = textgen(n, 0)
+    nb = (n + zl.BLOCK - 1) // zl.BLOCK
+    with zl.Stream(0, 0, True, nb) as s:
+        z = s.encode(x)
+    with zl.Stream(0, 0, False, nb) as d:
+        back = d.decode(z, n)
+    assert back.size == n
+    assert hashlib.sha256(back.tobytes()).digest() == hashlib.sha256(x.tobytes()).digest()

@@ -56,3 +56,21 @@ def test_length_tables_tie_heavy(oracle, ref):
         else: f = np.maximum(0, rng.normal(3, 3, n)).astype(np.int64)
         f = np.asarray(f, dtype=np.uint32)
         assert np.array_equal(oracle.length_table(f, limit), ref.length_table(f, limit)), it
+
+
+def test_deterministic_corrupt_streams_oracle_vs_reference():
+    """The three Huffman validity checks (src/libzling.cpp:381, 391, 398) on streams built to hit each one: the oracle's code
+    must correspond to the reference's exception.  (The rlen-cut case is the one documented deviation: the reference writes the
+    index entry past rlen and goes on, the restatement refuses it as 'bad ex-bits'.)"""
+    from corpus import corrupt_cases
+    from oracle_py import Oracle, Reference
+    o, r = Oracle(), Reference()
+    x, cases = corrupt_cases(o)
+    msgs = {}
+    for name, bad, ocode in cases:
+        assert o.decode(bad, x.size)[0] == ocode
+        rc, _, msg = r.decode(bad, x.size)
+        msgs[name] = (rc, msg)
+    assert msgs["code1"][0] == -2 and "bad code1" in msgs["code1"][1]
+    assert msgs["code2"][0] == -2 and "bad code2" in msgs["code2"][1]
+    assert msgs["exbits"][0] in (0, -2)              # reference: decodes on, or fails later in the ROLZ replay

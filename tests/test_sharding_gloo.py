@@ -1,9 +1,12 @@
-"""world_size-2 (and 3) CPU test of the block-range sharding protocol over gloo.
+"""world_size-2 (and 3) CPU tests of the block-range sharding protocol over gloo.
 
 The GPU stream object is replaced by a fake with the same interface whose codec is the oracle, so
-this checks the host logic that bench.py / multi-GPU callers run: range planning, parse-before-state,
-the 64 KiB MTF hand-off, and that the concatenated rank outputs equal the single-stream encoding.
+this checks the host logic that bench.py / multi-GPU callers run: range planning, per-rank batching over
+several contexts (RangeEncoder), parse-before-state, the hand-off of the 64 KiB MTF tables AND of
+current_level (src/libzling.cpp:185, 261-266), and that the concatenated rank outputs equal the
+single-stream encoding -- at e0 and at e4 with a range that ENDS on an incompressible sub-block.
 """
+import ctypes as C
 import os
 import sys
 
@@ -20,89 +23,147 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 from libzling_amd import sharding  # noqa: E402
 
+BLOCK = sharding.BLOCK
+_u8p = C.POINTER(C.c_uint8)
+
 
 class FakeStream:
-    """Stream-shaped wrapper over the oracle's zo_stream (parse is a no-op: the oracle parses in finish)."""
+    """Stream-shaped wrapper over the oracle's zo_stream, with "device pointers" that are host addresses.
+    parse_device only records the range (the oracle parses inside finish); the state calls round-trip both
+    the tables and current_level, like zlng_{get,set}_state_device."""
 
-    def __init__(self, level):
-        import ctypes as C
+    def __init__(self, level, blocks):
         from oracle_py import Oracle
-        self.C = C
         self.o = Oracle()
         self.h = self.o.lib.zo_stream_new(level)
         self.level = level
+        self.max_blocks = blocks
+        self.pending = None
 
-    def set_state(self, mtf, level):
-        m = np.ascontiguousarray(mtf, np.uint8)
-        self.o.lib.zo_stream_set_mtf(self.h, m.ctypes.data_as(self.C.POINTER(self.C.c_uint8)))
+    def close(self):
+        pass
 
-    def get_state(self):
-        m = np.empty(65536, np.uint8)
-        self.o.lib.zo_stream_get_mtf(self.h, m.ctypes.data_as(self.C.POINTER(self.C.c_uint8)))
-        return m, self.level
+    def parse_device(self, ptr, n):
+        assert (n + BLOCK - 1) // BLOCK <= self.max_blocks
+        self.pending = (ptr, n)
 
-    def encode(self, x):
-        C = self.C
-        cap = self.o.lib.zo_encode_bound(x.size)
-        out = np.empty(cap, np.uint8)
-        n = C.c_size_t(0)
-        rc = self.o.lib.zo_encode_blocks(self.h, x.ctypes.data_as(C.POINTER(C.c_uint8)), x.size,
-                                         out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n))
+    def set_state_device(self, ptr, level):
+        assert level in (0, self.level)
+        self.o.lib.zo_stream_set_mtf(self.h, C.cast(ptr, _u8p))
+        self.o.lib.zo_stream_set_level(self.h, level)
+
+    def get_state_device(self, ptr):
+        self.o.lib.zo_stream_get_mtf(self.h, C.cast(ptr, _u8p))
+        return self.o.lib.zo_stream_get_level(self.h)
+
+    def finish_device(self, out_ptr, cap):
+        ptr, n = self.pending
+        self.pending = None
+        got = C.c_size_t(0)
+        rc = self.o.lib.zo_encode_blocks(self.h, C.cast(ptr, _u8p), n, C.cast(out_ptr, _u8p), cap, C.byref(got))
         assert rc == 0
-        return out[: n.value].copy()
+        return got.value
+
+    def timings(self):
+        return []
 
 
-def _worker(rank, world, port, total, tmp):
+def make_input(kind, total):
+    from oracle_py import textgen
+    if kind == "text":
+        return textgen(total, 90)
+    # "mixed": text, with an incompressible stretch that covers the END of the first block range and the start of the
+    # next one, so at e1-e4 the first range ends at current_level 0 and the next one must start there
+    x = textgen(total, 91)
+    rng = np.random.Generator(np.random.PCG64(7))
+    edge = sharding.plan(total, 2)[1][0]                     # where rank 1's range starts in the world-2 test
+    lo, hi = edge - 700_000, min(total, edge + 200_000)
+    x[lo:hi] = rng.integers(0, 256, hi - lo, dtype=np.uint8)
+    return x
+
+
+def _worker(rank, world, port, total, tmp, kind, level, ctx_blocks):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle_py import textgen
     off, n = sharding.plan(total, world)[rank]
-    x = textgen(total, 90)[off:off + n]           # every rank generates the same stream, keeps its range
-    s = FakeStream(0)
-    init, lv0 = FakeStream(0).get_state()
-    buf = torch.empty(65536, dtype=torch.uint8)
-    order = []
-    out = {}
+    x = np.ascontiguousarray(make_input(kind, total)[off:off + n])      # every rank generates the same stream, keeps its range
+    nb = (n + BLOCK - 1) // BLOCK
+    enc = sharding.RangeEncoder(lambda blocks: FakeStream(level, blocks), nb, ctx_blocks)
+    assert len(enc.streams) == (nb + ctx_blocks - 1) // ctx_blocks
+    out = np.empty(FakeStream(level, 1).o.lib.zo_encode_bound(n) + 64, np.uint8)
+    state = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8)           # this rank's state buffer ("device" = host here)
+    buf = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8)             # the exchanged buffer
+    init_level = FakeStream(level, 1).get_state_device(state.data_ptr())
+    order, entry = [], {}
 
     def parse():
         order.append("parse")
+        enc.parse(x.ctypes.data, n)
 
-    def finish():
-        order.append("finish")
-        out["z"] = s.encode(x)
-        return out["z"].size
-
-    def to_buf(b):
-        m, lv = s.get_state()
-        b.copy_(torch.from_numpy(m))
-        return lv
-
-    def from_buf(b, lv):
+    def load_state(b):
         order.append("state")
-        s.set_state(b.numpy(), lv)
+        state.copy_(b)
+        entry["level"] = int(b[sharding.MTF_STATE].item())
+        return entry["level"]
 
-    sharding.run_handoff(s, rank, world, dist, buf, init, lv0, 0, parse, finish, to_buf, from_buf)
+    def finish(lv):
+        order.append("finish")
+        return enc.finish(out.ctypes.data, out.size, state.data_ptr(), lv)
+
+    def store_state(b, lv):
+        b.copy_(state)
+        b[sharding.MTF_STATE] = lv
+
+    segs, lv_out = sharding.run_handoff(enc, rank, world, dist, buf, parse, finish, load_state, store_state, init_level)
     assert order[0] == "parse" and order[-1] == "finish"
-    out["z"].tofile(os.path.join(tmp, "part%d.zlng" % rank))
+    z = np.concatenate([out[o:o + k] for o, k in segs])
+    z.tofile(os.path.join(tmp, "part%d.zlng" % rank))
+    with open(os.path.join(tmp, "level%d.txt" % rank), "w") as f:
+        f.write("%d %d" % (entry.get("level", -1), lv_out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total", [(2, 2 * sharding.BLOCK + 123_457), (3, 3 * sharding.BLOCK - 5)])
-def test_block_range_sharding_equals_single_stream(tmp_path, world, total):
-    port = 29500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
-    from oracle_py import Oracle, textgen
-    whole = Oracle().encode(textgen(total, 90), 0)
+@pytest.mark.parametrize("world,total,kind,level,ctx_blocks", [
+    (2, 2 * BLOCK + 123_457, "text", 0, 240),
+    (3, 3 * BLOCK - 5, "text", 0, 240),
+    (2, 2 * BLOCK + 300_000, "mixed", 4, 240),          # rank 0's range ends incompressible: rank 1 must enter at level 0
+    (2, 4 * BLOCK + 50_000, "text", 0, 1),              # per-rank batching: 2-3 contexts of one block per rank
+])
+def test_block_range_sharding_equals_single_stream(tmp_path, world, total, kind, level, ctx_blocks):
+    port = 29500 + (os.getpid() % 2000) + world + 7 * level + ctx_blocks % 5
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path), kind, level, ctx_blocks), nprocs=world, join=True)
+    from oracle_py import Oracle
+    whole = Oracle().encode(make_input(kind, total), level)
     parts = np.concatenate([np.fromfile(os.path.join(str(tmp_path), "part%d.zlng" % r), dtype=np.uint8) for r in range(world)])
     assert np.array_equal(parts, whole)
+    if kind == "mixed":
+        entered, _ = (int(v) for v in open(os.path.join(str(tmp_path), "level1.txt")).read().split())
+        assert entered == 0, "rank 1 must receive current_level 0 from a range that ended incompressible"
+
+
+def test_handoff_refuses_a_buffer_without_room_for_the_level():
+    with pytest.raises(AssertionError):
+        sharding.run_handoff(None, 0, 1, None, torch.zeros(65536, dtype=torch.uint8), lambda: None, lambda lv: (None, lv),
+                             lambda b: 0, lambda b, lv: None, 0)
 
 
 def test_plan_is_block_aligned_and_covers():
-    for total in (1, sharding.BLOCK, 10 ** 9, 8 * 10 ** 9 + 7):
+    for total in (1, BLOCK, 10 ** 9, 8 * 10 ** 9 + 7):
         for world in (1, 2, 4, 8):
             p = sharding.plan(total, world)
             assert sum(n for _, n in p) == total
-            assert all(off % sharding.BLOCK == 0 or off == total for off, _ in p)
+            assert all(off % BLOCK == 0 or off == total for off, _ in p)
             assert all(p[i][0] + p[i][1] == p[i + 1][0] for i in range(world - 1))
+
+
+def test_split_blocks():
+    assert sharding.split_blocks(512, 128) == [128] * 4
+    assert sharding.split_blocks(512, 240) == [171, 171, 170]
+    assert sharding.split_blocks(60, 128) == [60]
+    assert sharding.split_blocks(0, 128) == []
+    for n in range(1, 700, 37):
+        for c in (1, 7, 128, 240):
+            p = sharding.split_blocks(n, c)
+            assert sum(p) == n and max(p) <= c and max(p) - min(p) <= 1
