@@ -44,23 +44,25 @@ __global__ __launch_bounds__(256) void k_histogram(HuffArgs a) {
 // tie-break key, src/libzling_huffman.cpp:63-67), so the libstdc++ binary-heap primitives
 // (GCC 11 bits/stl_heap.h: __push_heap :134-147, __adjust_heap :223-248, __pop_heap :253-265,
 // __make_heap :339-360) are restated over an LDS array.  A heap entry packs (weight << 11 | node)
-// so one LDS read yields both; comparisons look at the weight only.
+// into 64 bits so one LDS read yields both (any 32-bit weight sum is exact, not only the <= 262,144
+// symbols of a real sub-block); comparisons look at the weight only.
 // The build is inherently serial (one lane); the wavefront's other lanes help with the
 // embarrassingly parallel parts (leaf setup, depth -> length, totals).
 constexpr int kHeapNodeBits = 11;                    // node ids < 1027 < 2048
-__device__ __forceinline__ uint32_t hw(uint32_t e) { return e >> kHeapNodeBits; }
+typedef unsigned long long HeapEnt;
+__device__ __forceinline__ uint32_t hw(HeapEnt e) { return (uint32_t)(e >> kHeapNodeBits); }
 
-__device__ __forceinline__ void heap_sift_up(uint32_t* h, int hole, int top, uint32_t v) {
+__device__ __forceinline__ void heap_sift_up(HeapEnt* h, int hole, int top, HeapEnt v) {
     int parent = (hole - 1) / 2;
     while (hole > top && hw(h[parent]) > hw(v)) { h[hole] = h[parent]; hole = parent; parent = (hole - 1) / 2; }
     h[hole] = v;
 }
-__device__ __forceinline__ void heap_adjust(uint32_t* h, int hole, int len, uint32_t v) {
+__device__ __forceinline__ void heap_adjust(HeapEnt* h, int hole, int len, HeapEnt v) {
     const int top = hole;
     int kid = hole;
     while (kid < (len - 1) / 2) {
         kid = 2 * (kid + 1);
-        const uint32_t r = h[kid], l = h[kid - 1];
+        const HeapEnt r = h[kid], l = h[kid - 1];
         if (hw(r) > hw(l)) { kid--; h[hole] = l; } else { h[hole] = r; }
         hole = kid;
     }
@@ -73,7 +75,7 @@ __device__ __forceinline__ void heap_adjust(uint32_t* h, int hole, int len, uint
 }
 
 // Builds lengths for one alphabet.  freq/len are LDS arrays of n entries.  Runs on lane 0.
-__device__ void build_lengths_lane0(const uint32_t* freq, uint8_t* len, int n, int limit, uint32_t* heap,
+__device__ void build_lengths_lane0(const uint32_t* freq, uint8_t* len, int n, int limit, HeapEnt* heap,
                                     uint16_t* kid0, uint16_t* kid1, uint16_t* leafsym, uint8_t* depth) {
     for (int i = 0; i < n; i++) len[i] = 0;
     for (int scaling = 0;; scaling++) {
@@ -83,23 +85,23 @@ __device__ void build_lengths_lane0(const uint32_t* freq, uint8_t* len, int n, i
             if (f > 0) {
                 const uint32_t w = (f + ((1u << scaling) - 1)) >> scaling;
                 leafsym[nn] = (uint16_t)i;
-                heap[nn] = w << kHeapNodeBits | (uint32_t)nn;
+                heap[nn] = (HeapEnt)w << kHeapNodeBits | (uint32_t)nn;
                 nn++;
             }
         }
         if (nn == 0) return;
         const int nleaf = nn;
         int hn = nn;
-        if (hn >= 2) for (int p = (hn - 2) / 2; p >= 0; p--) { const uint32_t v = heap[p]; heap_adjust(heap, p, hn, v); }
+        if (hn >= 2) for (int p = (hn - 2) / 2; p >= 0; p--) { const HeapEnt v = heap[p]; heap_adjust(heap, p, hn, v); }
         while (hn > 1) {
-            const uint32_t e1 = heap[0];
-            { const uint32_t v = heap[hn - 1]; heap[hn - 1] = e1; heap_adjust(heap, 0, hn - 1, v); hn--; }
-            const uint32_t e2 = heap[0];
-            if (hn > 1) { const uint32_t v = heap[hn - 1]; heap[hn - 1] = e2; heap_adjust(heap, 0, hn - 1, v); }
+            const HeapEnt e1 = heap[0];
+            { const HeapEnt v = heap[hn - 1]; heap[hn - 1] = e1; heap_adjust(heap, 0, hn - 1, v); hn--; }
+            const HeapEnt e2 = heap[0];
+            if (hn > 1) { const HeapEnt v = heap[hn - 1]; heap[hn - 1] = e2; heap_adjust(heap, 0, hn - 1, v); }
             hn--;
             kid0[nn] = (uint16_t)(e1 & ((1u << kHeapNodeBits) - 1));
             kid1[nn] = (uint16_t)(e2 & ((1u << kHeapNodeBits) - 1));
-            const uint32_t e = (hw(e1) + hw(e2)) << kHeapNodeBits | (uint32_t)nn;
+            const HeapEnt e = (HeapEnt)(hw(e1) + hw(e2)) << kHeapNodeBits | (uint32_t)nn;
             heap_sift_up(heap, hn, 0, e);
             hn++;
             nn++;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64) void k_lengths(HuffArgs a) {
     __shared__ uint32_t freq[kNsymAll];
     __shared__ uint8_t  len[kNsymAll + 2];
     __shared__ uint16_t code[kNsymAll];
-    __shared__ uint32_t heap[kNsym1];
+    __shared__ HeapEnt heap[kNsym1];
     __shared__ uint16_t kid0[2 * kNsym1], kid1[2 * kNsym1], leafsym[kNsym1];
     __shared__ uint8_t  depth[2 * kNsym1];
     const uint32_t blk = blockIdx.y + a.blk0, sub = blockIdx.x;

@@ -31,12 +31,14 @@ for it in range(2):
         print("   %-14s %10.3f ms" % (name, ms))
 if os.environ.get("ZLNG_PROFILE") == "1":
     import ctypes as C
-    buf = (C.c_ulonglong * (16 * nb))()
+    SL = 24
+    buf = (C.c_ulonglong * (SL * nb))()
     zl.lib().zlng_debug_counters(C.c_void_p(s._h), buf, nb)
     for b in range(min(nb, 4)):
-        d = buf[16 * b: 16 * b + 8]
-        e = buf[16 * b + 8: 16 * b + 16]
-        print("   validate %.0f cyc/round, commit %.0f cyc/round" % (e[7] / max(d[3], 1), e[3] / max(d[3], 1)))
+        d = buf[SL * b: SL * b + 8]
+        e = buf[SL * b + 8: SL * b + 24]
+        print("   validate %.0f cyc/round, commit %.0f cyc/round, segments/round %.2f, problem tokens/round: conflict %.3f word-candidate %.3f" % (
+            e[7] / max(d[3], 1), e[8] / max(d[3], 1), d[5] / max(d[3], 1), d[6] / max(d[3], 1), d[7] / max(d[3], 1)))
         print("   conflicts: same-key %d ring %d lazy-only %d | exact replays %d of which result == speculation %d" % (e[2], e[3], e[4], e[5], e[6]))
         print("   serial-token cycles %.0fM (%.0f per problem token), chase %.0fM (%.0f per round)" % (e[0] / 1e6, e[0] / max(d[6] + d[7], 1), e[1] / 1e6, e[1] / max(d[3], 1)))
         tot = d[0] + d[1] + d[2]

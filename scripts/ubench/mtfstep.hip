@@ -256,6 +256,69 @@ __global__ void k_p12(unsigned* out) {
     FIN
 }
 
+// P13: P12 without the rank record (state-only chain; ranks recomputed per tile in parallel from table snapshots)
+#define P13BODY(B, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_sdwa vcc, %[pk], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "v_cmp_eq_u32_sdwa %[m1], %[pk], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "s_cbranch_scc0 1f\n\t1: " \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t"
+__global__ void k_p13(unsigned* out) {
+    DECL unsigned pk = 0x0d060a03u;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("s_cmp_eq_u32 0, 0\n\t"
+                     P13BODY(0, 0) P13BODY(1, 1) P13BODY(2, 2) P13BODY(3, 3)
+                     : [t0] "+v"(t0), [m1] "=&s"(m1), [up] "+v"(up) : [pk] "s"(pk) : "vcc", "scc", "s90", "s91");
+    }
+    FIN
+}
+// P14: P13 with the slow-path test on the vcc of a compare restricted to lanes 0..20 by EXEC (s_cbranch_vccz, no s_andn2):
+//      the restricted compare is an extra v_cmp_eq under a narrowed exec -- does swapping SALU for VALU + exec writes pay?  (6 + 2 exec writes)
+#define P14BODY(B, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_sdwa vcc, %[pk], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "v_cmp_eq_u32_sdwa %[m1], %[pk], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t" \
+    "s_cbranch_scc0 1f\n\t1: "
+__global__ void k_p14(unsigned* out) {
+    DECL unsigned pk = 0x0d060a03u;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile(P14BODY(0, 0) P14BODY(1, 1) P14BODY(2, 2) P14BODY(3, 3)
+                     : [t0] "+v"(t0), [m1] "=&s"(m1), [up] "+v"(up) : [pk] "s"(pk) : "vcc", "scc", "s90", "s91");
+    }
+    FIN
+}
+// P15: P13 but one slow-path test per TWO literals: both one-hot words must be non-zero (s_min_u32 of the two, then s_cmp)
+#define P15PAIR(B0, B1) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_sdwa vcc, %[pk], %[t0] src0_sel:BYTE_" #B0 " src1_sel:DWORD\n\t" \
+    "v_cmp_eq_u32_sdwa %[m1], %[pk], %[up] src0_sel:BYTE_" #B0 " src1_sel:DWORD\n\t" \
+    "s_cbranch_scc0 1f\n\t1: " \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t" \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ne_u32_sdwa vcc, %[pk], %[t0] src0_sel:BYTE_" #B1 " src1_sel:DWORD\n\t" \
+    "v_cmp_eq_u32_sdwa %[m1], %[pk], %[up] src0_sel:BYTE_" #B1 " src1_sel:DWORD\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "s_andn2_b64 s[92:93], 0x1fffff, vcc\n\t" \
+    "s_min_u32 s90, s90, s92\n\t" \
+    "s_cmp_lg_u32 s90, 0\n\t"
+__global__ void k_p15(unsigned* out) {
+    DECL unsigned pk = 0x0d060a03u;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("s_cmp_eq_u32 0, 0\n\t"
+                     P15PAIR(0, 1) P15PAIR(2, 3)
+                     : [t0] "+v"(t0), [m1] "=&s"(m1), [up] "+v"(up) : [pk] "s"(pk) : "vcc", "scc", "s90", "s91", "s92", "s93");
+    }
+    FIN
+}
+
 template <class F> static double run(F launch) {
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     float best = 1e30f;
@@ -291,5 +354,8 @@ int main(int argc, char** argv) {
     RUN("P10 P4 + one-hot rank record (9)", k_p10)
     RUN("P11 P10 + late branch (9)", k_p11)
     RUN("P12 P11 + SDWA packed literals (8)", k_p12)
+    RUN("P13 P12 without rank record (7)", k_p13)
+    RUN("P14 P13, branch right after its andn2 (7)", k_p14)
+    RUN("P15 P13, one test per two literals (7.5)", k_p15)
     return 0;
 }
