@@ -312,6 +312,82 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
           [p15] "s"(pk[15])                                                                                     \
         : "vcc", "scc", "s98", "s99", "m0")
 
+// ---- state-only form of the tile (what the hottest chains run).  The serial chain is bound by instructions per literal
+// (scripts/ubench/mtfstep.hip: 19.1 ns per literal with the rank record, 17.0 without; the two SALU instructions that
+// are left -- slow-path test and its late branch -- cost 6.4 ns of that, the five-instruction table chain alone 10.7),
+// so the chain wavefront only carries the TABLE forward: no v_writelane of the rank.  It leaves a snapshot of t0 per
+// tile instead, and k_mtf_replay recomputes the ranks of every tile from its snapshot -- thousands of tiles at once.
+// Differences from ZLNG_MTF_G_STEP / _SLOW: no rank record; the out-of-line part of step K first notes K + 1 in lv, so a
+// literal of rank >= 64 (leave) is identified without the rank word (lv is cleared again at label 264 on the normal way out).
+// (DPP hazard, gfx9: a VALU write of t0 must be >= 2 wait states ahead of a DPP read of it.  Without the rank record only
+//  s_andn2 follows the step's last select, so the plain compare of the next step goes FIRST and the DPP move second.)
+#define ZLNG_MTF_S_STEP(PK, B, K, KP)                                                                           \
+    "2" #K ":\n\t"                                                                                              \
+    "v_cmp_ne_u32_sdwa vcc, %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_cmp_eq_u32_sdwa %[m1], %[" #PK "], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                        \
+    "s_cbranch_scc0 1" #KP "f\n\t"                                                                              \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                      \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t"                                                          \
+    "s_andn2_b64 s[98:99], 0x1fffff, vcc\n\t"
+#define ZLNG_MTF_S_SLOW(PK, B, K, KN)                                                                           \
+    "1" #K ":\n\t"                                                                                              \
+    "s_mov_b32 %[lv], " #K "+1\n\t"                                                                             \
+    "v_cmp_eq_u32_sdwa vcc, %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
+    "s_bfe_u32 %[d], %[" #PK "], (8 * " #B ") | (8 << 16)\n\t"                                                  \
+    "s_cbranch_vccz 9f\n\t"                                                                                     \
+    "s_ff1_i32_b64 %[nx], vcc\n\t"                                                                              \
+    "s_add_u32 %[i], %[nx], 1\n\t"                                                                              \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "s_mul_i32 %[nx], %[i], 0xf337\n\t"                                                                         \
+    "v_readlane_b32 %[da], %[t0], %[i]\n\t"                                                                     \
+    "s_lshr_b32 %[nx], %[nx], 16\n\t"                                                                           \
+    "v_readlane_b32 %[db], %[t0], %[nx]\n\t"                                                                    \
+    "v_writelane_b32 %[t0], %[da], m0\n\t"                                                                      \
+    "s_mov_b32 m0, %[i]\n\t"                                                                                    \
+    "v_writelane_b32 %[t0], %[db], m0\n\t"                                                                      \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
+    "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
+    "s_branch 2" #KN "b\n\t"
+#define ZLNG_MTF_S_FAST(PK, Z, A, B, C, D)                                                                      \
+    ZLNG_MTF_S_STEP(PK, 0, A, Z) ZLNG_MTF_S_STEP(PK, 1, B, A) ZLNG_MTF_S_STEP(PK, 2, C, B) ZLNG_MTF_S_STEP(PK, 3, D, C)
+#define ZLNG_MTF_S_COLD(PK, A, B, C, D, N)                                                                      \
+    ZLNG_MTF_S_SLOW(PK, 0, A, B) ZLNG_MTF_S_SLOW(PK, 1, B, C) ZLNG_MTF_S_SLOW(PK, 2, C, D) ZLNG_MTF_S_SLOW(PK, 3, D, N)
+#define ZLNG_MTF_TILE_S()                                                                                       \
+    asm volatile(                                                                                               \
+        "s_load_dwordx16 %[nxt], %[ptr], 0x40\n\t"                                                              \
+        "s_cmp_eq_u32 0, 0\n\t"                                                                                 \
+        ZLNG_MTF_S_FAST(p0, 19, 0, 1, 2, 3)      ZLNG_MTF_S_FAST(p1, 3, 4, 5, 6, 7)                             \
+        ZLNG_MTF_S_FAST(p2, 7, 8, 9, 10, 11)     ZLNG_MTF_S_FAST(p3, 11, 12, 13, 14, 15)                        \
+        ZLNG_MTF_S_FAST(p4, 15, 16, 17, 18, 19)  ZLNG_MTF_S_FAST(p5, 19, 20, 21, 22, 23)                        \
+        ZLNG_MTF_S_FAST(p6, 23, 24, 25, 26, 27)  ZLNG_MTF_S_FAST(p7, 27, 28, 29, 30, 31)                        \
+        ZLNG_MTF_S_FAST(p8, 31, 32, 33, 34, 35)  ZLNG_MTF_S_FAST(p9, 35, 36, 37, 38, 39)                        \
+        ZLNG_MTF_S_FAST(p10, 39, 40, 41, 42, 43) ZLNG_MTF_S_FAST(p11, 43, 44, 45, 46, 47)                       \
+        ZLNG_MTF_S_FAST(p12, 47, 48, 49, 50, 51) ZLNG_MTF_S_FAST(p13, 51, 52, 53, 54, 55)                       \
+        ZLNG_MTF_S_FAST(p14, 55, 56, 57, 58, 59) ZLNG_MTF_S_FAST(p15, 59, 60, 61, 62, 63)                       \
+        "264:\n\t"                                                                                              \
+        "s_cbranch_scc0 163f\n\t"                                                                               \
+        "s_mov_b32 %[lv], 0\n\t"                                                                                \
+        "s_branch 9f\n\t"                                                                                       \
+        ZLNG_MTF_S_COLD(p0, 0, 1, 2, 3, 4)       ZLNG_MTF_S_COLD(p1, 4, 5, 6, 7, 8)                             \
+        ZLNG_MTF_S_COLD(p2, 8, 9, 10, 11, 12)    ZLNG_MTF_S_COLD(p3, 12, 13, 14, 15, 16)                        \
+        ZLNG_MTF_S_COLD(p4, 16, 17, 18, 19, 20)  ZLNG_MTF_S_COLD(p5, 20, 21, 22, 23, 24)                        \
+        ZLNG_MTF_S_COLD(p6, 24, 25, 26, 27, 28)  ZLNG_MTF_S_COLD(p7, 28, 29, 30, 31, 32)                        \
+        ZLNG_MTF_S_COLD(p8, 32, 33, 34, 35, 36)  ZLNG_MTF_S_COLD(p9, 36, 37, 38, 39, 40)                        \
+        ZLNG_MTF_S_COLD(p10, 40, 41, 42, 43, 44) ZLNG_MTF_S_COLD(p11, 44, 45, 46, 47, 48)                       \
+        ZLNG_MTF_S_COLD(p12, 48, 49, 50, 51, 52) ZLNG_MTF_S_COLD(p13, 52, 53, 54, 55, 56)                       \
+        ZLNG_MTF_S_COLD(p14, 56, 57, 58, 59, 60) ZLNG_MTF_S_COLD(p15, 60, 61, 62, 63, 64)                       \
+        "9:\n\t"                                                                                                \
+        "s_waitcnt lgkmcnt(0)"                                                                                  \
+        : [t0] "+v"(t0), [up] "+v"(up), [m1] "=&s"(m1_), [i] "=&s"(i_), [nx] "=&s"(nx_),                        \
+          [d] "=&s"(d_), [da] "=&s"(da_), [db] "=&s"(db_), [lv] "=&s"(lv_), [nxt] "=&s"(nxt)                    \
+        : [ptr] "s"(tile_ptr), [p0] "s"(pk[0]), [p1] "s"(pk[1]), [p2] "s"(pk[2]), [p3] "s"(pk[3]),              \
+          [p4] "s"(pk[4]), [p5] "s"(pk[5]), [p6] "s"(pk[6]), [p7] "s"(pk[7]), [p8] "s"(pk[8]), [p9] "s"(pk[9]), \
+          [p10] "s"(pk[10]), [p11] "s"(pk[11]), [p12] "s"(pk[12]), [p13] "s"(pk[13]), [p14] "s"(pk[14]),        \
+          [p15] "s"(pk[15])                                                                                     \
+        : "vcc", "scc", "s98", "s99", "m0")
+
 __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     const uint32_t ctx = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -334,6 +410,8 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
 
     uint32_t up = 0xFFFFFFFFu;                                         // ZLNG_MTF_TILE: t0 shifted down one lane
     uint8_t* run = a.lit_byte + a.ctx_off[ctx];                       // 64-byte aligned (k_ctx_offsets)
+    uint8_t* snap = a.snap + a.ctx_off[ctx];
+    uint8_t* tile_kk = a.tile_kk + (a.ctx_off[ctx] >> 6);
     const uint32_t n = a.ctx_total[ctx];
     typedef uint32_t Tile16 __attribute__((ext_vector_type(16)));
     Tile16 pk;
@@ -345,20 +423,21 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
             Tile16 nxt;
             uint32_t i_, nx_, d_, da_, db_, lv_;
             uint64_t m1_;
-            ZLNG_MTF_TILE();
+            snap[base + lane] = (uint8_t)t0;                             // table front at the start of the tile, for k_mtf_replay
+            ZLNG_MTF_TILE_S();
             pk = nxt;
-            const uint32_t rec = ranks;                                  // one-hot word, 0x80000000 | rank, 0 or the fill
-            ranks = (rec & 0x80000000u) ? (rec & 0xFFu) : (uint32_t)__builtin_ctz(rec | 0x40000000u);
-            if (__builtin_expect(lv_ != 0, 0)) {                         // a literal of rank >= 64 stopped the statement
+            uint32_t kk = 64;                                            // literals of this tile whose ranks the replay computes
+            if (__builtin_expect(lv_ != 0, 0)) {                         // literal lv_ - 1 has rank >= 64: the statement stopped there
 #define RANKSTORE(I, K) wrl(ranks, I, K)
+                kk = lv_ - 1;
                 const uint32_t v = run[base + lane];
-                const uint32_t kk = (uint32_t)__builtin_ctzll(__ballot(rec == 0u));
                 const uint32_t r = slow_step(rdl(v, kk));
                 wrl(ranks, r, kk);
                 for (uint32_t k = kk + 1; k < 64u; k++) ZLNG_MTF_STEP(k)
 #undef RANKSTORE
+                if (lane >= kk) run[base + lane] = (uint8_t)ranks;       // lanes below kk keep their literal for the replay
             }
-            run[base + lane] = (uint8_t)ranks;
+            if (lane == 0) tile_kk[base >> 6] = (uint8_t)kk;
         } else {
 #define RANKSTORE(I, K) wrl(ranks, I, K)
             const uint32_t cnt = n - base;
@@ -366,9 +445,32 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
             for (uint32_t k = 0; k < cnt; k++) ZLNG_MTF_STEP(k)
 #undef RANKSTORE
             if (lane < cnt) run[base + lane] = (uint8_t)ranks;
+            if (lane == 0) tile_kk[base >> 6] = 0;
         }
     }
     st[lane] = (uint8_t)t0; st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
+}
+
+// ------------------------------------------------------------------------------ K2d'
+// Ranks of the tiles k_mtf_dense walked in its state-only form: one wavefront per tile replays the tile's first
+// tile_kk literals from the table front the chain left in `snap` (all of them have rank < 64, so the front is all
+// the state there is) and records their ranks in place.  Tiles are independent: the whole chip works on them.
+__global__ __launch_bounds__(256) void k_mtf_replay(MtfArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t end = (size_t)a.ctx_off[255] + (((size_t)a.ctx_total[255] + 63) & ~(size_t)63);
+    if (tile * 64 >= end) return;
+    const uint32_t kk = a.tile_kk[tile];
+    if (kk == 0) return;
+    uint32_t t0 = a.snap[tile * 64 + lane];
+    uint8_t* run = a.lit_byte + tile * 64;
+    const uint32_t v = run[lane];
+    uint32_t ranks = 0;
+    auto slow_step = [&](uint32_t) -> uint32_t { return 255u; };       // unreachable: these literals have rank < 64
+#define RANKSTORE(I, K) wrl(ranks, I, K)
+    for (uint32_t k = 0; k < kk; k++) ZLNG_MTF_STEP(k)
+#undef RANKSTORE
+    if (lane < kk) run[lane] = (uint8_t)ranks;
 }
 
 void launch_mtf_rank(const MtfArgs& a, hipStream_t s) {
@@ -379,6 +481,8 @@ void launch_mtf_rank(const MtfArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_ctx_offsets, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_lit_tiles<kModeScatter>, tiles, dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_mtf_dense, dim3(256), dim3(64), 0, s, a);
+    const size_t max_tiles = ((size_t)a.nblocks * a.tok_cap + 256 * 64) / 64;
+    hipLaunchKernelGGL(k_mtf_replay, dim3((unsigned)((max_tiles + 3) / 4)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_lit_tiles<kModeGather>, tiles, dim3(64), 0, s, a);
 }
 

@@ -1,0 +1,341 @@
+// rolz_dev.h -- device helpers shared by the ROLZ parser kernels (rolz_parse.hip, rolz_pipe.hip): the exact
+// MatchAndUpdate / MatchLazy restatements, the per-position speculation of a window, and the small lane utilities.
+// Internal to libzlng_hip.so.
+#pragma once
+#include "zlng_common.h"
+#include "zlng_kernels.h"
+
+namespace zlng {
+
+// ------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// HashContext, src/libzling_lz.cpp:55-57
+__device__ __forceinline__ uint32_t hash4(const uint8_t* p) {
+    uint32_t w = ld32u(p);
+    return w + ((w >> 16) & 0xFF) * 137u + (w >> 24) * 13337u;
+}
+
+// GetCommonLength, src/libzling_lz.cpp:66-89: 0 unless 4 bytes agree, else byte-wise LCP capped at 259.
+__device__ __forceinline__ int common_len(const uint8_t* a, const uint8_t* b) {
+    if (ld32u(a) != ld32u(b)) return 0;
+    int n = 4;
+    while (n + 4 <= kMatchMax) {
+        uint32_t x = ld32u(a + n) ^ ld32u(b + n);
+        if (x) return n + (__ffs((int)x) - 1) / 8;
+        n += 4;
+    }
+    while (n < kMatchMax && a[n] == b[n]) n++;
+    return n;
+}
+
+// One context's dictionary plane.  Fields are addressed as (wave-uniform base) + (32-bit byte offset): the whole
+// per-block dictionary is 10 MiB, so the offset fits a VGPR and every access is a global_load/store with an SGPR
+// base ("saddr") -- no 64-bit per-lane pointer arithmetic.
+template <class T> struct BktField {
+    uint8_t* d; uint32_t o;
+    __device__ __forceinline__ T& operator[](uint32_t i) const { return *reinterpret_cast<T*>(d + (o + (uint32_t)sizeof(T) * i)); }
+};
+struct Bucket {
+    BktField<uint32_t> offset; BktField<uint16_t> suffix; BktField<uint16_t> hash;
+    __device__ __forceinline__ Bucket(uint8_t* dict, uint32_t ctx) {
+        const uint32_t b = ctx * kBktBytes;
+        offset = {dict, b + kBktOffsetOff};
+        suffix = {dict, b + kBktSuffixOff};
+        hash   = {dict, b + kBktHashOff};
+    }
+};
+
+// MatchLazy, src/libzling_lz.cpp:291-316
+__device__ __forceinline__ bool lazy_probe(uint8_t* dict, const uint8_t* buf, int pos, int maxlen, int depth) {
+    Bucket B(dict, buf[pos - 1]);
+    uint32_t node = B.hash[hash4(buf + pos) % kHashSlots];
+    if (node == 65535) return false;
+    int m = maxlen - 3;
+    for (int i = 0; i < depth; i++) {
+        uint32_t off = B.offset[node] & 0xFFFFFF;
+        if (ld32u(buf + pos + m) == ld32u(buf + off + m)) return true;
+        node = B.suffix[node];
+        if (node == 65535 || off <= (B.offset[node] & 0xFFFFFF)) break;
+    }
+    return false;
+}
+
+// MatchAndUpdate, src/libzling_lz.cpp:211-289 (insert first, then walk <= depth chain nodes).
+// `head` is the ring slot this insert takes (the caller owns the per-context head counters).
+// Safe to run wave-uniformly: every lane computes the same thing, lane 0 alone stores.
+__device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, int pos, const LevelCfg cfg,
+                                            uint32_t head, bool writer, int& match_idx, int& match_len) {
+    uint32_t h = hash4(buf + pos);
+    uint32_t chk = (h / kHashSlots) & 255u;
+    uint32_t hc = h % kHashSlots;
+    uint32_t ctx = buf[pos - 1];
+    Bucket B(dict, ctx);
+    uint32_t node = B.hash[hc];
+    if (writer) {
+        B.suffix[head] = (uint16_t)node;
+        B.offset[head] = (uint32_t)pos | chk << 24;
+        B.hash[hc] = (uint16_t)head;
+    }
+    if (node == 65535 || node == head) return false;
+
+    int maxlen = kMatchMin - 1;
+    uint32_t maxnode = 0;
+    for (int i = 0; i < cfg.depth; i++) {
+        // the slot just written is read back as written (it is `head`, checked above for i == 0;
+        // later hits on it end the chain through the position test exactly as in the reference)
+        uint32_t ov = node == head ? ((uint32_t)pos | chk << 24) : B.offset[node];
+        uint32_t off = ov & 0xFFFFFF;
+        if ((ov >> 24) == chk && buf[pos + maxlen] == buf[off + maxlen]) {
+            int len = common_len(buf + pos, buf + off);
+            if (len > maxlen) { maxnode = node; maxlen = len; if (maxlen == kMatchMax) break; }
+        }
+        uint32_t nx = B.suffix[node];
+        if (nx == 65535) break;
+        uint32_t noff = nx == head ? (uint32_t)pos : (B.offset[nx] & 0xFFFFFF);
+        if (off <= noff) break;
+        node = nx;
+    }
+    if (maxlen < kMatchMin) return false;
+    if (maxlen < kLazyLimit) {
+        if (cfg.lazy1 > 0 && lazy_probe(dict, buf, pos + 1, maxlen, cfg.lazy1)) return false;
+        if (cfg.lazy2 > 0 && lazy_probe(dict, buf, pos + 2, maxlen, cfg.lazy2)) return false;
+    }
+    match_len = maxlen;
+    match_idx = (int)((head - maxnode) & (kRing - 1));
+    return true;
+}
+
+
+constexpr int kKeyTab = 4096;                        // 64-bit lane masks, indexed by a hash of (ctx, hash13)
+constexpr int kEvTab = 4096;                         // 64-bit lane masks, indexed by a hash of (key byte, word)
+
+__device__ __forceinline__ uint32_t key_ix(uint32_t ctx, uint32_t hc) { return (hc ^ (ctx * 0x9E5u)) & (kKeyTab - 1); }
+__device__ __forceinline__ uint32_t ev_ix(uint32_t key, uint32_t word) { return (word ^ (word >> 7) ^ (key * 0x2D1u)) & (kEvTab - 1); }
+__device__ __forceinline__ uint32_t ring_dist(uint32_t node, uint32_t head0) { return (node - head0 - 1u) & (kRing - 1); }
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int lane) {
+    return (unsigned long long)rl((uint32_t)(v >> 32), lane) << 32 | rl((uint32_t)v, lane);
+}
+__device__ __forceinline__ uint32_t ufl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t hash_of(uint32_t w) { return w + ((w >> 16) & 0xFF) * 137u + (w >> 24) * 13337u; }
+__device__ __forceinline__ int top_bit(unsigned long long m) { return 63 - __clzll((long long)m); }     // m != 0
+
+// packed speculative result of one lane
+constexpr uint32_t kSpLenMask = 0x1FF;               // bits 0..8  maxlen (3 = none)
+constexpr int      kSpNodeShift = 9;                 // bits 9..20 maxnode
+constexpr uint32_t kSpVeto1 = 1u << 21, kSpVeto2 = 1u << 22, kSpCanMatch = 1u << 23;
+constexpr uint32_t kSpRisk1 = 1u << 25, kSpRisk2 = 1u << 26;   // lazy read set near the ring head
+constexpr int      kMinRestart = 12;                 // restart a round at a conflict only if it resolved >= 12 positions
+constexpr uint32_t kRiskDist = 64;                   // a round hands out <= 64 slots per context
+
+// token kinds (also the "previous token" kind carried to the next boundary)
+constexpr uint32_t kTyNone = 0, kTyLit = 1, kTyW0 = 2, kTyW1 = 3, kTyMatch = 4;
+
+struct Quad { uint32_t a, b, c, d; };
+__device__ __forceinline__ Quad ld128u(const uint8_t* p) { Quad q; __builtin_memcpy(&q, p, 16); return q; }
+
+// byte-wise common prefix of a and b, capped at 259, given that it is going to be compared with
+// a threshold >= 3: returns 0 when the first four bytes differ (GetCommonLength, src/libzling_lz.cpp:66-89).
+__device__ __forceinline__ int common_len_q(const uint8_t* a, const uint8_t* b, const Quad qa) {
+    const Quad qb = ld128u(b);
+    uint32_t x = qa.a ^ qb.a;
+    if (x) return 0;
+    x = qa.b ^ qb.b; if (x) return 4 + (__ffs((int)x) - 1) / 8;
+    x = qa.c ^ qb.c; if (x) return 8 + (__ffs((int)x) - 1) / 8;
+    x = qa.d ^ qb.d; if (x) return 12 + (__ffs((int)x) - 1) / 8;
+    int n = 16;
+    while (n + 4 <= kMatchMax) {
+        x = ld32u(a + n) ^ ld32u(b + n);
+        if (x) return n + (__ffs((int)x) - 1) / 8;
+        n += 4;
+    }
+    while (n < kMatchMax && a[n] == b[n]) n++;
+    return n;
+}
+
+// Speculative evaluation of one position as a token start (phase 1 of the parser, also run ahead of
+// it by the prefetch wavefront): hash head, <= depth chain nodes with exact LCP, lazy probes.
+// Read-only on the dictionary.  `dmin` = ring distance (ahead of the context's head) of the nearest
+// visited node; lz*/lkix*/lctx* describe the lazy probes' read sets.
+struct Spec {
+    uint32_t sp, node0, head0, dmin;
+    uint32_t lkix1, lkix2, lctx1, lctx2;
+    uint32_t ld1, ld2;                   // ring distance (ahead of the probe bucket's head) of the nearest node a lazy probe visited
+    bool lz1, lz2;
+    // level 0 only, for resolving same-slot conflicts in registers: candidate length of the first chain node
+    // alone, the lazy probe's source offset (bit 31: probe chain non-empty), the 16 input bytes at the position
+    uint32_t len0, lsrc1;
+    Quad qa;
+};
+
+__device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
+    const uint32_t x0 = qa.a ^ qb.a, x1 = qa.b ^ qb.b, x2 = qa.c ^ qb.c, x3 = qa.d ^ qb.d;
+    uint32_t len = x3 ? 12u + ((uint32_t)__ffs((int)x3) - 1u) / 8u : 16u;
+    len = x2 ? 8u + ((uint32_t)__ffs((int)x2) - 1u) / 8u : len;
+    len = x1 ? 4u + ((uint32_t)__ffs((int)x1) - 1u) / 8u : len;
+    return x0 ? 0u : len;
+}
+__device__ __forceinline__ uint32_t lcp_tail(const uint8_t* a, const uint8_t* b, bool active) {   // continue an LCP of 16
+    uint32_t n = 16;
+    while (__any(active)) {
+        if (active) {
+            if (n + 4 <= (uint32_t)kMatchMax) {
+                const uint32_t x = ld32u(a + n) ^ ld32u(b + n);
+                if (x) { n += ((uint32_t)__ffs((int)x) - 1u) / 8u; active = false; } else n += 4;
+            } else if (n < (uint32_t)kMatchMax && a[n] == b[n]) n++;
+            else active = false;
+        }
+    }
+    return n;
+}
+
+
+// Generic-depth form (levels 1-4: depth 4..16, lazy depths up to 4 and 2; src/libzling_lz.cpp:131-134).  Loops run
+// wave-uniformly (`while any lane is still walking`) with per-lane predicates instead of per-lane breaks: a divergent
+// break costs a handful of exec-mask instructions per lane group, a uniform loop costs one scalar branch.
+__device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, int ppos, uint32_t lctx, uint32_t first, uint32_t lov,
+                                            uint32_t lsfx, uint32_t m, int depth, uint32_t lhead, bool active, bool& veto, uint32_t& ld) {
+    // (n, lov = offset[n], lsfx = suffix[n]) travel together, so a chain hop is ONE round trip: the source word
+    // of node n and both ring fields of its successor are requested at the same time
+    Bucket B(dict, lctx);
+    uint32_t n = first;
+    active = active && n != 65535u;
+    const uint32_t probe = ld32u(buf + ppos + m);
+    for (int i = 0; i < depth && __any(active); i++) {
+        if (active) ld = min(ld, ring_dist(n, lhead));
+        const uint32_t off = lov & 0xFFFFFF;
+        const uint32_t srcw = ld32u(buf + (active ? off + m : (uint32_t)ppos));
+        const uint32_t nn = lsfx;
+        const uint32_t nov = B.offset[nn & (kRing - 1)];
+        const uint32_t nsfx = B.suffix[nn & (kRing - 1)];
+        if (active && probe == srcw) { veto = true; active = false; }
+        active = active && nn != 65535u;
+        if (active) ld = min(ld, ring_dist(nn, lhead));
+        active = active && !(off <= (nov & 0xFFFFFF));
+        n = nn; lov = nov; lsfx = nsfx;
+    }
+}
+
+// head0 / lhead1 / lhead2: ring heads of the position's bucket and of the two probe buckets as the caller read them;
+// risk_dist: a probe that visited a node within this many slots ahead of its bucket's head gets the kSpRisk flag.
+__device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t lhead2,
+                                          uint32_t risk_dist, int pos,
+                                          const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
+    const uint32_t w4 = qa.a;                        // qa: bytes pos .. pos+15, loaded by the caller (pos+275 < ilen)
+    const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
+    const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
+    Bucket B(dict, ctx), B1(dict, lctx1), B2(dict, lctx2);
+    const uint32_t node0 = B.hash[hc];
+    const uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
+    const uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
+    uint32_t ov = B.offset[node0 & (kRing - 1)];
+    uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
+    const uint32_t lsf1 = B1.suffix[ln1 & (kRing - 1)], lsf2 = B2.suffix[ln2 & (kRing - 1)];
+
+    uint32_t maxlen = kMatchMin - 1, maxnode = 0, node = node0, dmin = kRing - 1;
+    bool active = node0 != 65535u;
+    for (int i = 0; i < cfg.depth && __any(active); i++) {                 // src/libzling_lz.cpp:240-267
+        if (active) dmin = min(dmin, ring_dist(node, head0));
+        const uint32_t off = ov & 0xFFFFFF;
+        const bool cmp = active && (ov >> 24) == chk;
+        const Quad qb = ld128u(buf + (cmp ? off : (uint32_t)pos));
+        const uint32_t nov = B.offset[nx & (kRing - 1)];
+        const uint32_t nnx = B.suffix[nx & (kRing - 1)];
+        uint32_t len = cmp ? lcp16(qa, qb) : 0u;
+        const bool lng = cmp && len == 16u;
+        if (__any(lng)) { const uint32_t t = lcp_tail(buf + pos, buf + off, lng); len = lng ? t : len; }
+        if (len > maxlen) { maxlen = len; maxnode = node; }
+        active = active && maxlen != (uint32_t)kMatchMax && nx != 65535u;
+        if (active) dmin = min(dmin, ring_dist(nx, head0));
+        active = active && !(off <= (nov & 0xFFFFFF));
+        node = nx; ov = nov; nx = nnx;
+    }
+    uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
+    const bool lz = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
+    const uint32_t m = lz ? maxlen - 3u : 0u;
+    bool v1 = false, v2 = false;
+    uint32_t ld1 = kRing - 1, ld2 = kRing - 1;
+    if (want1) lazy_spec_u(dict, buf, pos + 1, lctx1, ln1, lov1, lsf1, m, cfg.lazy1, lhead1, lz, v1, ld1);
+    if (want2) lazy_spec_u(dict, buf, pos + 2, lctx2, ln2, lov2, lsf2, m, cfg.lazy2, lhead2, lz, v2, ld2);
+    if (v1) sp |= kSpVeto1;
+    if (v2) sp |= kSpVeto2;
+    if (ld1 < risk_dist) sp |= kSpRisk1;
+    if (ld2 < risk_dist) sp |= kSpRisk2;
+    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
+    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = key_ix(lctx2, hh2); S.lctx1 = lctx1; S.lctx2 = lctx2;
+    S.ld1 = ld1; S.ld2 = ld2;
+    S.lz1 = lz && want1; S.lz2 = lz && want2;
+}
+
+// Level-0 form of speculate() (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130): the same
+// semantics written as straight-line predicated code.  Every divergent if / break in the generic form costs
+// a handful of exec-mask instructions, and one wavefront issues an instruction only every few cycles, so on
+// the level the benchmark runs the generic form spends most of phase 1 on control flow rather than on the
+// five dependent memory round trips.  Only the >16-byte tail of a long match keeps a (wave-uniform) loop.
+__device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t risk_dist, int pos,
+                                             const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
+    const uint32_t w4 = qa.a;
+    const uint32_t lctx1 = w4 & 0xFF;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    Bucket B(dict, ctx), B1(dict, lctx1);
+    // round trip 1: both hash heads
+    const uint32_t node0 = B.hash[hc];
+    const uint32_t ln1 = B1.hash[hh1];
+    const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
+    // round trip 2: ring entries of the first nodes
+    const uint32_t ov0 = B.offset[node0 & (kRing - 1)];
+    const uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)];
+    const uint32_t off0 = ov0 & 0xFFFFFF;
+    // round trip 3: compare bytes of node 0 and the ring entry of node 1
+    const bool cmp0 = has0 && (ov0 >> 24) == chk;
+    const Quad q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
+    const uint32_t nov = B.offset[nx & (kRing - 1)];
+    uint32_t len0 = cmp0 ? lcp16(qa, q0) : 0u;
+    const bool long0 = cmp0 && len0 == 16u;
+    if (__any(long0)) { const uint32_t t = lcp_tail(buf + pos, buf + off0, long0); len0 = long0 ? t : len0; }
+    uint32_t maxlen = kMatchMin - 1, maxnode = 0;
+    if (len0 > maxlen) { maxlen = len0; maxnode = node0; }
+    // chain continues to node 1?  (src/libzling_lz.cpp:255-266)
+    const bool has1 = has0 && maxlen != (uint32_t)kMatchMax && nx != 65535u;
+    const uint32_t off1 = nov & 0xFFFFFF;
+    const bool go1 = has1 && !(off0 <= off1);
+    // round trip 4: compare bytes of node 1
+    const bool cmp1 = go1 && (nov >> 24) == chk;
+    const Quad q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
+    uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
+    const bool long1 = cmp1 && len1 == 16u;
+    if (__any(long1)) { const uint32_t t = lcp_tail(buf + pos, buf + off1, long1); len1 = long1 ? t : len1; }
+    if (len1 > maxlen) { maxlen = len1; maxnode = nx; }
+    uint32_t dmin = kRing - 1;
+    dmin = has0 ? min(dmin, ring_dist(node0, head0)) : dmin;
+    dmin = has1 ? min(dmin, ring_dist(nx, head0)) : dmin;          // its offset was read for the chain-end test
+    uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
+    // round trip 5: the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1)
+    const bool lz1 = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
+    const uint32_t m = lz1 ? maxlen - 3u : 0u;
+    const uint32_t probe = ld32u(buf + ((uint32_t)pos + 1u + m));
+    const uint32_t srcw = ld32u(buf + ((lz1 && hasl) ? (lov1 & 0xFFFFFF) + m : (uint32_t)pos));
+    if (lz1 && hasl && probe == srcw) sp |= kSpVeto1;
+    const uint32_t ld1 = hasl ? ring_dist(ln1, lhead1) : (uint32_t)kRing - 1u;
+    if (ld1 < risk_dist) sp |= kSpRisk1;                                  // (kept even when no probe was needed: the conflict fix may need one)
+    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
+    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = 0; S.lctx1 = lctx1; S.lctx2 = 0;
+    S.ld1 = ld1; S.ld2 = kRing - 1;
+    S.lz1 = lz1; S.lz2 = false;
+    S.len0 = len0; S.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u); S.qa = qa;
+}
+
+// Ordering point for LDS traffic inside ONE wavefront (program order is execution order for a wave's LDS
+// operations; this only stops the compiler from moving accesses across it).  The parser's workgroup also
+// holds a prefetch wavefront that never joins a barrier, so the main wavefront must not use s_barrier.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace zlng

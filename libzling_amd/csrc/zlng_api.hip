@@ -71,6 +71,8 @@ struct zlng_ctx {
     uint32_t* d_ctx_total = nullptr;
     uint32_t* d_ctx_off = nullptr;
     uint8_t*  d_lit_byte = nullptr;
+    uint8_t*  d_snap = nullptr;       // rank stage: table snapshots per 64-literal tile
+    uint8_t*  d_tile_kk = nullptr;
     // decode pools
     DecSub*   d_subs = nullptr;
     DecBlock* d_blocks = nullptr;
@@ -90,7 +92,8 @@ struct zlng_ctx {
     uint32_t pending_blocks = 0;
 
     StageTimer timer;
-    int parser_kind = 0;              // 0 = wavefront-speculative (default), 1 = serial cross-check form
+    int parser_kind = 2;              // 2 = single-wavefront speculative parser (default), 1 = serial cross-check form (ZLNG_PARSER=serial),
+                                      // 0 = pipelined evaluator + resolver wavefronts (ZLNG_PARSER=pipe; exact, measured slower -- DESIGN.md)
 };
 
 namespace {
@@ -164,12 +167,13 @@ uint32_t* overflow_flag(zlng_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_s
 
 // (Re)allocate the pools whose size follows the token capacity per block.
 int alloc_token_pools(zlng_ctx* c, uint32_t tok_cap) {
-    for (void* p : {(void*)c->d_tok, (void*)c->d_tile_hist, (void*)c->d_lit_byte}) if (p) hipFree(p);
-    c->d_tok = nullptr; c->d_tile_hist = nullptr; c->d_lit_byte = nullptr;
+    for (void* p : {(void*)c->d_tok, (void*)c->d_tile_hist, (void*)c->d_lit_byte, (void*)c->d_snap, (void*)c->d_tile_kk}) if (p) hipFree(p);
+    c->d_tok = nullptr; c->d_tile_hist = nullptr; c->d_lit_byte = nullptr; c->d_snap = nullptr; c->d_tile_kk = nullptr;
     const size_t nb = c->max_blocks;
     int rc;
     if ((rc = dev_alloc(c, &c->d_tok, nb * tok_cap)) || (rc = dev_alloc(c, &c->d_tile_hist, nb * (tok_cap / 4096) * 256)) ||
-        (rc = dev_alloc(c, &c->d_lit_byte, nb * tok_cap + 256 * 64 + 128)))      // + run alignment + one tile of read-ahead
+        (rc = dev_alloc(c, &c->d_lit_byte, nb * tok_cap + 256 * 64 + 128)) ||    // + run alignment + one tile of read-ahead
+        (rc = dev_alloc(c, &c->d_snap, nb * tok_cap + 256 * 64 + 128)) || (rc = dev_alloc(c, &c->d_tile_kk, (nb * tok_cap + 256 * 64) / 64 + 8)))
         return rc;
     c->tok_cap = tok_cap;
     return ZLNG_OK;
@@ -180,11 +184,14 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
     static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
     static const int pf_waves = getenv("ZLNG_PF_WAVES") ? std::min(3, std::max(1, atoi(getenv("ZLNG_PF_WAVES")))) : 1;
+    static const int pipe_lead = getenv("ZLNG_PIPE_LEAD") ? atoi(getenv("ZLNG_PIPE_LEAD")) : 2;
+    static const int pipe_pf = getenv("ZLNG_PIPE_PF") ? atoi(getenv("ZLNG_PIPE_PF")) : 1;
     ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
                  c->tok_cap, blk0, overflow_flag(c)};
     launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream);
     timer_mark(c, "dict_reset");
     if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
+    else if (c->parser_kind == 0) { pa.pf_ahead = pipe_lead; pa.pf_waves = pipe_pf; launch_rolz_parse_pipe(pa, nb, c->stream, c->level == 0); }
     else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
     timer_mark(c, "rolz_parse");
 }
@@ -200,7 +207,7 @@ int run_back(zlng_ctx* c, uint32_t nb, uint32_t g0, uint8_t* d_out, size_t out_c
     for (uint32_t b = g0 * G, g = g0; b < nb; b += G, g++) {
         const uint32_t n = std::min(G, nb - b);
         MtfArgs ma{c->d_tok + (size_t)b * c->tok_cap, c->d_ntok + b, n, c->tok_cap, c->d_mtf, c->d_tile_base, c->d_tile_hist,
-                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte};
+                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk};
         launch_mtf_rank(ma, c->stream);
         if (b + G < nb)        // tables at the start of the next group
             CTX_HIP(hipMemcpyAsync(c->d_mtf_snap + (size_t)(g + 1) * ZLNG_MTF_STATE, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
@@ -383,7 +390,7 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     c->is_encode = is_encode != 0;
     c->max_blocks = (uint32_t)max_blocks;
     const char* pk = getenv("ZLNG_PARSER");
-    c->parser_kind = (pk && strcmp(pk, "serial") == 0) ? 1 : 0;
+    c->parser_kind = !pk ? 2 : (strcmp(pk, "serial") == 0 ? 1 : (strcmp(pk, "pipe") == 0 ? 0 : 2));
     int rc = ZLNG_OK;
     auto fail = [&](int code) { *err = code; zlng_destroy(c); return (zlng_ctx*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return fail(ZLNG_E_DEVICE);
@@ -437,7 +444,7 @@ void zlng_destroy(zlng_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
                     c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_snap, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring, c->d_tile_base, c->d_tile_hist,
-                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte};
+                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);

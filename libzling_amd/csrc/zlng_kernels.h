@@ -26,6 +26,7 @@ void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s);
 // both parse blocks [a.blk0, nblocks)
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
 void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);
+void launch_rolz_parse_pipe(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);   // pf_ahead = evaluator lead (windows)
 
 // ---- K2 ------------------------------------------------------------------------------
 struct MtfArgs {
@@ -39,6 +40,8 @@ struct MtfArgs {
     uint32_t*       ctx_total; // [256]
     uint32_t*       ctx_off;   // [256] start of each context's dense run
     uint8_t*        lit_byte;  // dense literal bytes, context-major, stream order inside a context; ranks in place
+    uint8_t*        snap;      // table front (64 B) at the start of every 64-literal tile of lit_byte (same indexing)
+    uint8_t*        tile_kk;   // per tile: literals whose ranks k_mtf_replay computes from the snapshot (0 = none)
 };
 void launch_mtf_rank(const MtfArgs& a, hipStream_t s);
 

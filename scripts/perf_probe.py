@@ -37,6 +37,10 @@ if os.environ.get("ZLNG_PROFILE") == "1":
     for b in range(min(nb, 4)):
         d = buf[SL * b: SL * b + 8]
         e = buf[SL * b + 8: SL * b + 24]
+        if os.environ.get("ZLNG_PARSER") == "pipe":
+            print("blk %d pipe: rounds %d, wait %.0f cyc/round, resolve %.0f cyc/round, segments/round %.2f, conflicts/round %.3f (stale %.3f), word-candidates/round %.3f" % (
+                b, d[3], d[0] / max(d[3], 1), d[2] / max(d[3], 1), d[5] / max(d[3], 1), d[6] / max(d[3], 1), e[9] / max(d[3], 1), d[7] / max(d[3], 1)))
+            continue
         print("   validate %.0f cyc/round, commit %.0f cyc/round, segments/round %.2f, problem tokens/round: conflict %.3f word-candidate %.3f" % (
             e[7] / max(d[3], 1), e[8] / max(d[3], 1), d[5] / max(d[3], 1), d[6] / max(d[3], 1), d[7] / max(d[3], 1)))
         print("   conflicts: same-key %d ring %d lazy-only %d | exact replays %d of which result == speculation %d" % (e[2], e[3], e[4], e[5], e[6]))

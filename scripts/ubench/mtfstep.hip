@@ -258,8 +258,8 @@ __global__ void k_p12(unsigned* out) {
 
 // P13: P12 without the rank record (state-only chain; ranks recomputed per tile in parallel from table snapshots)
 #define P13BODY(B, K) \
-    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
     "v_cmp_ne_u32_sdwa vcc, %[pk], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
     "v_cmp_eq_u32_sdwa %[m1], %[pk], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
     "s_cbranch_scc0 1f\n\t1: " \
     "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
@@ -319,6 +319,27 @@ __global__ void k_p15(unsigned* out) {
     FIN
 }
 
+// P16: state-only chain whose slow-path test stays on the vector unit: after the speculative neighbour swap c sits at lane
+//      rank-1 (or 0), so "c is within lanes 0..19 of the NEW table" <=> rank <= 20.  tl = table with lanes >= 20 blanked
+//      (one v_cndmask with a constant lane mask), v_cmp_eq -> VCC, s_cbranch_vccz taken two instructions late.  No SALU ALU op.
+#define P16BODY(B, K) \
+    "v_mov_b32_dpp %[up], %[t0] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_eq_u32_sdwa %[m1], %[pk], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "s_cbranch_vccz 1f\n\t1: " \
+    "v_cmp_ne_u32_sdwa vcc, %[pk], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "v_cndmask_b32_dpp %[t0], %[t0], %[t0], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[up], %[m1]\n\t" \
+    "v_cndmask_b32_e64 %[tl], %[t0], %[ff], %[hi]\n\t" \
+    "v_cmp_eq_u32_sdwa vcc, %[pk], %[tl] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"
+__global__ void k_p16(unsigned* out) {
+    DECL unsigned pk = 0x0d060a03u, tl, ff = 0xffffffffu; unsigned long long hi = ~0xfffffull;
+    for (int it = 0; it < ITER; it++) {
+        asm volatile("v_cmp_eq_u32_e32 vcc, %[t0], %[t0]\n\t"
+                     P16BODY(0, 0) P16BODY(1, 1) P16BODY(2, 2) P16BODY(3, 3)
+                     : [t0] "+v"(t0), [m1] "=&s"(m1), [up] "+v"(up), [tl] "=&v"(tl) : [pk] "s"(pk), [ff] "v"(ff), [hi] "s"(hi) : "vcc", "scc");
+    }
+    FIN
+}
 template <class F> static double run(F launch) {
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     float best = 1e30f;
@@ -357,5 +378,6 @@ int main(int argc, char** argv) {
     RUN("P13 P12 without rank record (7)", k_p13)
     RUN("P14 P13, branch right after its andn2 (7)", k_p14)
     RUN("P15 P13, one test per two literals (7.5)", k_p15)
+    RUN("P16 VALU-only slow test, blanked table (8)", k_p16)
     return 0;
 }

@@ -311,3 +311,28 @@ def test_failed_call_leaves_the_stream_state_untouched(zl, oracle):
         assert np.array_equal(np.concatenate([za, out[: n.value]]), ref)
         with pytest.raises(zl.ZlngError):
             s.set_state(before, 3)                                        # current_level is 0 or the context's level
+
+
+@pytest.mark.parametrize("parser", ["pipe", "serial"])
+def test_alternative_parsers_are_bit_exact(parser):
+    """The pipelined parser (rolz_pipe.hip: evaluator + resolver wavefronts, ZLNG_PARSER=pipe) and the one-lane serial form
+    are kept as cross-checks of the production parser: same bytes as the oracle at e0 and e4 on text with an incompressible
+    stretch and a sub-block cut inside a window.  (Own process: the parser is chosen when the context is created.)"""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r]
+import libzling_amd as zl
+from oracle_py import Oracle, textgen
+n = 2 * zl.BLOCK + 300_000 if %r == "pipe" else 700_000
+x = textgen(n, 17)
+x[n // 2: n // 2 + 400_000] = np.random.Generator(np.random.PCG64(3)).integers(0, 256, 400_000, dtype=np.uint8)
+o = Oracle()
+for lv in (0, 4):
+    assert np.array_equal(zl.encode(x, lv), o.encode(x, lv)), lv
+print("ok")
+''' % (os.path.dirname(G.rstrip("/")).rsplit("/tests", 1)[0], os.path.join(os.path.dirname(G.rstrip("/")).rsplit("/tests", 1)[0], "oracle"), parser)
+    env = dict(os.environ, ZLNG_PARSER=parser)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
