@@ -44,7 +44,8 @@ BLOCK = zl.BLOCK
 METRIC = "encode MB/s (input) at e0 on enwik9; bit-exact .zlng; 1/2/4/8 GPU"
 METRIC_DECODE = "decode MB/s (output) of the e0 enwik9 .zlng; bit-exact round trip; 1 GPU"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_OF_STAGE = {"rolz_parse": "k_rolz_parse_wave", "mtf_rank": "k_mtf_dense", "huff_pack": "k_pack", "huff_lengths": "k_lengths",
+RANK_STAGES = ("lit_partition", "mtf_chain", "rank_replay", "mtf_rank")      # one launch group: the first three; several: mtf_rank
+KERNEL_OF_STAGE = {"rolz_parse": "k_rolz_parse_wave", "mtf_rank": "k_mtf_dense", "mtf_chain": "k_mtf_dense", "rank_replay": "k_mtf_replay", "huff_pack": "k_pack", "huff_lengths": "k_lengths",
                    "histogram": "k_histogram", "huff_decode": "k_huff_decode", "rolz_decode": "k_rolz_decode", "frame_walk": "k_frame_walk"}
 
 
@@ -219,7 +220,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        sums = torch.tensor([float(n), float(out_len), stage.get("mtf_rank", 0.0),
+        sums = torch.tensor([float(n), float(out_len), sum(stage.get(k, 0.0) for k in RANK_STAGES),
                              sum(stage.get(k, 0.0) for k in ("histogram", "huff_lengths", "layout_scan", "huff_pack"))], dtype=torch.float64, device=cdev)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         mx = torch.tensor([stage.get("rolz_parse_max", 0.0)], dtype=torch.float64, device=cdev)
@@ -227,7 +228,7 @@ def main():
         total_in, total_out, rank_sum, huff_sum, parse_max = (float(sums[0]), float(sums[1]), float(sums[2]), float(sums[3]), float(mx[0]))
     else:
         total_in, total_out = float(n), float(out_len)
-        rank_sum = stage.get("mtf_rank", 0.0)
+        rank_sum = sum(stage.get(k, 0.0) for k in RANK_STAGES)
         huff_sum = sum(stage.get(k, 0.0) for k in ("histogram", "huff_lengths", "layout_scan", "huff_pack"))
         parse_max = stage.get("rolz_parse_max", 0.0)
 
@@ -282,7 +283,7 @@ def main():
                                              "GPU output prefix compared byte-for-byte" % (sample_n >> 20, args.level)}
             hot = enc.streams[-1].debug_fetch(8, 0, np.uint32, 256)
             if len(enc.parts) == 1 and args.level == 0:
-                res["rank_chain"] = rank_chain_line(x, args.level, int(hot.max()), stage.get("mtf_rank", 0.0))
+                res["rank_chain"] = rank_chain_line(x, args.level, int(hot.max()), stage.get("mtf_chain", 0.0))
         res["zlng_sha256_rank0"] = hashlib.sha256(got.tobytes()).hexdigest()
         print(json.dumps(res))
     if world > 1:

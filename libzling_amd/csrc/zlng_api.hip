@@ -208,11 +208,16 @@ int run_back(zlng_ctx* c, uint32_t nb, uint32_t g0, uint8_t* d_out, size_t out_c
         const uint32_t n = std::min(G, nb - b);
         MtfArgs ma{c->d_tok + (size_t)b * c->tok_cap, c->d_ntok + b, n, c->tok_cap, c->d_mtf, c->d_tile_base, c->d_tile_hist,
                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk};
-        launch_mtf_rank(ma, c->stream);
+        const bool single = G >= nb;                 // one group (always at level 0): time the serial chain by itself
+        launch_lit_partition(ma, c->stream);
+        if (single) timer_mark(c, "lit_partition");
+        launch_mtf_chain(ma, c->stream);
+        if (single) timer_mark(c, "mtf_chain");
+        launch_mtf_finish(ma, c->stream);
         if (b + G < nb)        // tables at the start of the next group
             CTX_HIP(hipMemcpyAsync(c->d_mtf_snap + (size_t)(g + 1) * ZLNG_MTF_STATE, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
     }
-    timer_mark(c, "mtf_rank");
+    timer_mark(c, G >= nb ? "rank_replay" : "mtf_rank");
     const HuffArgs ha = huff_args(c, nb, g0 * G, d_out, out_cap);
     launch_histogram(ha, c->stream);
     timer_mark(c, "histogram");

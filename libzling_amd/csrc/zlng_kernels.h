@@ -43,7 +43,9 @@ struct MtfArgs {
     uint8_t*        snap;      // table front (64 B) at the start of every 64-literal tile of lit_byte (same indexing)
     uint8_t*        tile_kk;   // per tile: literals whose ranks k_mtf_replay computes from the snapshot (0 = none)
 };
-void launch_mtf_rank(const MtfArgs& a, hipStream_t s);
+void launch_lit_partition(const MtfArgs& a, hipStream_t s);   // literals -> one dense run per context
+void launch_mtf_chain(const MtfArgs& a, hipStream_t s);       // k_mtf_dense: the serial chains
+void launch_mtf_finish(const MtfArgs& a, hipStream_t s);      // rank replay per tile + ranks back into the token words
 
 // ---- K3..K6 --------------------------------------------------------------------------
 struct HuffArgs {

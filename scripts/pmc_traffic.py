@@ -4,7 +4,19 @@
     python scripts/pmc_traffic.py fetch_results.db write_results.db bytes level blocks > profiles/rNN_pmc_traffic.json
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): the counters are in
 KB (1024 B) and FETCH_SIZE counts 128-B requests as 64 B, so hbm_bytes = (2 * FETCH + WRITE) * 1024 per launch."""
-import json, re, sqlite3, sys
+import glob, hashlib, json, os, re, sqlite3, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha():
+    """Same identity bench.py computes: the profile is only quoted for the kernel sources it was taken on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
@@ -27,5 +39,6 @@ print(json.dumps({
     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), per-launch averages. "
             "Unit KB (1024 B); gfx950 FETCH_SIZE counts 128-B requests as 64 B, so hbm_bytes = (2*FETCH + WRITE)*1024 as the guide "
             "prescribes (calibrated in round 1 on k_dict_reset / k_pack / k_histogram); for the parser's narrow random reads the x2 is an upper estimate.",
+    "kernel_source_sha": kernel_source_sha(),
     "workload": {"bytes": int(sys.argv[3]), "level": int(sys.argv[4]), "blocks": int(sys.argv[5])},
     "kernels": kern}, indent=1))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end measurement set on the GPU box (one gpurun call): default bench with the CPU baseline, rocprofv3 kernel trace of
-# the same command, and the two PMC passes for HBM traffic.  Usage: scripts/profile_round.sh r01_d
+# the same command, and the two PMC passes for HBM traffic.  Usage: scripts/profile_round.sh r02_a
 set -u
 TAG=${1:-r01_x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
