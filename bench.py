@@ -237,6 +237,8 @@ def main():
         value = total_in * args.steps / dt / 1e6
         # dominant kernel of the last step on this rank, from the HIP events the library records on its own streams
         real = {k: v for k, v in stage.items() if k != "rolz_parse_max"}
+        if len(enc.parts) > 1:                                     # the parts' parses run side by side: one launch = the slowest of them
+            real["rolz_parse"] = stage.get("rolz_parse_max", 0.0)
         dom = max(real, key=real.get) if real else None
         dom_ms = real.get(dom, 0.0) if dom else 0.0
         alg_bytes = float(n) + float(out_len)                       # every input byte read once,
