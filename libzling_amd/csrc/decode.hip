@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void k_frame_walk(DecodeArgs a) {
             last_encpos = encpos;
         }
         if (err || !closed) { nsub = first_sub; break; }             // drop the incomplete block
-        a.blocks[nblk] = DecBlock{first_sub, nsub - first_sub, out_total, last_encpos, 0};
+        a.blocks[nblk] = DecBlock{first_sub, nsub - first_sub, out_total, last_encpos, 0, p};
         out_total += last_encpos;
         nblk++;
         used = p;
@@ -57,6 +57,8 @@ __global__ __launch_bounds__(64) void k_frame_walk(DecodeArgs a) {
     a.summary[2] = nblk;
     a.summary[3] = nsub;
     a.summary[4] = out_total;
+    a.summary[5] = nblk;
+    a.summary[6] = 0;
 }
 
 // ------------------------------------------------------------------------------ K8 Huffman decode
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
     __shared__ uint8_t  len[kNsymAll + 2];
     __shared__ uint16_t code[kNsymAll];
     const uint32_t s = blockIdx.x;
-    if (s >= (uint32_t)a.summary[3] || a.summary[1] != 0) return;
+    if (s >= (uint32_t)a.summary[3]) return;
     const DecSub sb = a.subs[s];
     const uint8_t* pay = a.z + sb.payload_off;
     const uint32_t lane = threadIdx.x;
@@ -164,10 +166,8 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
         if ((nt & 63) == 0) tok[nt - 64 + lane] = tokv;
     }
     if (lane < (nt & 63)) tok[(nt & ~63u) + lane] = tokv;
-    if (lane == 0) {
-        a.sub_ntok[s] = nt;
-        if (err) atomicCAS((unsigned long long*)&a.summary[1], 0ull, (unsigned long long)err);
-    }
+    // a failed sub-block is marked in its token count; the replay, which walks the stream in order, stops at the first one
+    if (lane == 0) a.sub_ntok[s] = err ? (0x80000000u | err) : nt;
 }
 
 // ------------------------------------------------------------------------------ K9 ROLZ + MTF replay
@@ -178,7 +178,6 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
     __shared__ uint32_t mru[256];
     __shared__ uint16_t heads[256];
     const uint32_t lane = threadIdx.x;
-    if (a.summary[1] != 0) return;
     const uint32_t nblk = (uint32_t)a.summary[2];
     for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(mtf)[i] = reinterpret_cast<const uint32_t*>(a.mtf_state)[i];
     __syncthreads();
@@ -187,6 +186,9 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
     for (uint32_t b = 0; b < nblk && !err; b++) {
         const DecBlock bk = a.blocks[b];
         uint8_t* out = a.out + bk.out_off;
+        // tables at the start of this block: if it fails, they are what the context keeps (the blocks before it are good and
+        // are reported; the caller meets the error again at the head of its next call, as the reference's loop would)
+        for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_snap)[i] = reinterpret_cast<const uint32_t*>(mtf)[i];
         for (uint32_t i = lane; i < 256u * kRing; i += 64) ring[i] = 0;    // Reset(), src/libzling_lz.cpp:378-386
         for (uint32_t i = lane; i < 256; i += 64) heads[i] = 0;
         __syncthreads();
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
             const DecSub sb = a.subs[bk.first_sub + k];
             const uint32_t* tok = a.tok + sb.tok_off;
             const uint32_t nt = a.sub_ntok[bk.first_sub + k];
+            if (nt & 0x80000000u) { err = nt & 0xFFFFu; break; }           // K8 rejected this sub-block's bitstream
             for (uint32_t i = lane; i < 256; i += 64) mru[i] = 0;
             __syncthreads();
             uint32_t ti = 0;
@@ -272,10 +275,12 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
             if (!err && opos != sb.encpos) err = (uint32_t)(-ZLNG_DEC_E_LZ);   // src/libzling_lz.cpp:371-373
             __syncthreads();
         }
+        if (err && lane == 0) { a.summary[5] = b; a.summary[6] = err; }
     }
     __syncthreads();
-    for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_state)[i] = reinterpret_cast<const uint32_t*>(mtf)[i];
-    if (lane == 0 && err) a.summary[1] = err;
+    const uint8_t* keep = err ? a.mtf_snap : mtf;                    // a failed block leaves the tables as it found them
+    __threadfence_block();
+    for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_state)[i] = reinterpret_cast<const uint32_t*>(keep)[i];
 }
 
 void launch_frame_walk(const DecodeArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, s, a); }

@@ -64,6 +64,7 @@ struct zlng_ctx {
                                       // when the call fails), [g] = where a level-schedule repair in group g restarts
     uint32_t  tok_cap = kTokCapDefault;   // token words per block the pools are sized for (grows once to kTokCapMax)
     bool      tokens_ranked = false;      // the pending parse's literals were already ranked in place by a failed finish
+    uint32_t  last_blocks = 0;            // blocks the last decode call produced
     int       last_passes = 0;            // parse passes the last encode call needed (1 + level-schedule repairs + pool growth)
     unsigned long long* d_dbg = nullptr;  // parser phase counters (ZLNG_PROFILE=1)
     uint32_t* d_tile_base = nullptr;
@@ -599,15 +600,19 @@ int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size
     timer_begin(c);
     DecodeArgs da{static_cast<const uint8_t*>(d_in), (uint64_t)in_len, c->max_blocks, c->max_blocks * kDecSubsPerBlock,
                   (uint64_t)c->max_blocks * ((uint64_t)kTokCapMax + 64), c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_tok, c->d_ring,
-                  c->d_mtf, static_cast<uint8_t*>(d_out), (uint64_t)out_cap, c->d_summary};
+                  c->d_mtf, c->d_mtf_snap, static_cast<uint8_t*>(d_out), (uint64_t)out_cap, c->d_summary};
+    // tables at call entry (second snapshot slot): the host entry point restores them when the caller's buffer is too small
+    CTX_HIP(hipMemcpyAsync(c->d_mtf_snap + ZLNG_MTF_STATE, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
     launch_frame_walk(da, c->stream);
     timer_mark(c, "frame_walk");
-    uint64_t sum[5] = {0, 0, 0, 0, 0};
+    uint64_t sum[7] = {0, 0, 0, 0, 0, 0, 0};
     CTX_HIP(hipMemcpyAsync(sum, c->d_summary, sizeof sum, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
-    if (sum[1]) return -(int)sum[1];
-    const uint32_t nblk = (uint32_t)sum[2], nsub = (uint32_t)sum[3];
-    if (nblk == 0) return ZLNG_E_TRUNC;                   // not even one complete block in the prefix
+    uint32_t nblk = (uint32_t)sum[2];
+    const uint32_t nsub = (uint32_t)sum[3];
+    // Complete blocks in front of a framing error are decoded and reported first, like the reference's loop, which emits
+    // every block before it throws (src/libzling.cpp:306-420); the caller meets the error at the head of its next call.
+    if (nblk == 0) return sum[1] ? -(int)sum[1] : ZLNG_E_TRUNC;      // not even one complete block in the prefix
     launch_huff_decode(da, nsub, c->stream);
     timer_mark(c, "huff_decode");
     launch_rolz_decode(da, c->stream);
@@ -616,10 +621,15 @@ int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size
     CTX_HIP(hipMemcpyAsync(c->h_blocks.data(), c->d_blocks, nblk * sizeof(DecBlock), hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
     CTX_HIP(hipGetLastError());
-    if (sum[1]) return -(int)sum[1];
-    *in_used = (size_t)sum[0];
-    *out_len = (size_t)sum[4];
+    const uint32_t bad = (uint32_t)sum[5];
+    if (bad < nblk) {                                                // block `bad` failed in the Huffman or the replay stage
+        if (bad == 0) return -(int)sum[6];
+        nblk = bad;                                                  // the blocks before it are good; the tables are those at its start
+    }
+    *in_used = (size_t)c->h_blocks[nblk - 1].z_end;
+    *out_len = (size_t)(c->h_blocks[nblk - 1].out_off + c->h_blocks[nblk - 1].size);
     if (per_block_out_end) for (uint32_t b = 0; b < nblk; b++) per_block_out_end[b] = (size_t)(c->h_blocks[b].out_off + c->h_blocks[b].size);
+    c->last_blocks = nblk;
     return ZLNG_OK;
 }
 
@@ -638,7 +648,12 @@ int zlng_decode_blocks(zlng_ctx* c, const uint8_t* in, size_t in_len, size_t* in
     size_t produced = 0;
     rc = zlng_decode_blocks_device(c, c->d_in, in_len, in_used, c->d_out, raw_cap, &produced, per_block_out_end);
     if (rc != ZLNG_OK) return rc;
-    if (produced > out_cap) { *in_used = 0; return ZLNG_E_CAP; }
+    if (produced > out_cap) {                                        // nothing is reported: put the stream state back
+        *in_used = 0;
+        CTX_HIP(hipMemcpyAsync(c->d_mtf, c->d_mtf_snap + ZLNG_MTF_STATE, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+        CTX_HIP(hipStreamSynchronize(c->stream));
+        return ZLNG_E_CAP;
+    }
     CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
     *out_len = produced;

@@ -78,7 +78,7 @@ constexpr int ZLNG_DEC_E_LIMIT = -1, ZLNG_DEC_E_FLAG = -10, ZLNG_DEC_E_BLOCKSIZE
 constexpr uint32_t kDecSubsPerBlock = 1024;      // sub-block table capacity per block of a decode call
 
 struct DecSub   { uint64_t payload_off, tok_off; uint32_t encpos, rlen, olen, blk; };
-struct DecBlock { uint32_t first_sub, nsub; uint64_t out_off; uint32_t size, pad; };
+struct DecBlock { uint32_t first_sub, nsub; uint64_t out_off; uint32_t size, pad; uint64_t z_end; };   // z_end: compressed bytes up to and including the block's 0x00
 struct DecodeArgs {
     const uint8_t* z;          // compressed bytes
     uint64_t       z_len;
@@ -90,9 +90,11 @@ struct DecodeArgs {
     uint32_t*      tok;
     uint32_t*      ring;       // [256][4096] ZlingDecodeBucket::offset (src/libzling_lz.h:132-135)
     uint8_t*       mtf_state;  // 256 x 256, persists across calls
+    uint8_t*       mtf_snap;   // 256 x 256 scratch: tables at the start of the block being replayed (restored when it fails)
     uint8_t*       out;
     uint64_t       out_cap;
-    uint64_t*      summary;    // [0] bytes consumed [1] error (positive code) [2] blocks [3] sub-blocks [4] output bytes
+    uint64_t*      summary;    // [0] bytes consumed [1] frame error behind the complete blocks (positive code) [2] complete blocks
+                               // [3] sub-blocks [4] output bytes [5] first block that failed in K8/K9 (== [2] if none) [6] its error code
 };
 void launch_frame_walk(const DecodeArgs& a, hipStream_t s);
 void launch_huff_decode(const DecodeArgs& a, uint32_t nsubs, hipStream_t s);

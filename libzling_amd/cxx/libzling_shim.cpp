@@ -267,16 +267,18 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
         handler->OnInit();
     }
     {
-        const int nb = std::min(batch_blocks(), 16);
+        const int nb = std::min(batch_blocks(), 64);
         CtxGuard ctx(make_ctx(0, false, nb));
         // A .zlng stream has no index: the compressed bytes are pulled in chunks, whole blocks found in
         // the accumulated prefix are decoded, the unconsumed tail is kept for the next round.
         std::vector<unsigned char> z, raw((size_t)nb * kBlock);
         std::vector<size_t> ends((size_t)nb);
         const size_t chunk = 8u << 20;
-        bool failed = false, eof = false;
+        size_t zoff = 0;                                  // consumed prefix of z (compacted now and then, not per round)
+        bool failed = false, eof = false, closed_tail = false;
         while (!failed) {
             if (!eof) {
+                if (zoff > (z.size() >> 1)) { z.erase(z.begin(), z.begin() + (long)zoff); zoff = 0; }
                 size_t old = z.size();
                 z.resize(old + chunk);
                 size_t got = 0;
@@ -285,24 +287,34 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
                 if (inputter->IsErr()) { failed = true; break; }
                 eof = inputter->IsEnd();
             }
-            if (z.empty()) break;
+            if (z.size() == zoff) break;
             size_t used = 0, produced = 0;
-            int rc = zlng_decode_blocks(ctx.c, z.data(), z.size(), &used, raw.data(), raw.size(), &produced, ends.data());
+            std::fill(ends.begin(), ends.end(), (size_t)0);
+            int rc = zlng_decode_blocks(ctx.c, z.data() + zoff, z.size() - zoff, &used, raw.data(), raw.size(), &produced, ends.data());
+            if (rc == ZLNG_E_TRUNC && eof && !closed_tail) {
+                // The reference's inner loop also ends at end of input (src/libzling.cpp:312-313), so a final block without
+                // its 0x00 terminator is still decoded and written: close it and look again.
+                z.push_back(0);
+                closed_tail = true;
+                continue;
+            }
             if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
             if (rc == ZLNG_E_TRUNC && !eof) { continue; }            // need more bytes for the next block
             if (rc != ZLNG_OK) throw std::runtime_error(zlng_strerror(rc));
+            // whole good blocks only (a corrupt block is met again, alone, at the head of the next call and throws there --
+            // after every block before it went out, like the reference, src/libzling.cpp:412-419)
             size_t prev = 0;
-            for (size_t b = 0; b < ends.size() && prev < produced; b++) {   // src/libzling.cpp:412-419
+            for (size_t b = 0; b < ends.size() && prev < produced; b++) {
                 if (!push_all(outputter, raw.data() + prev, ends[b] - prev)) { failed = true; break; }
                 if (handler) handler->OnProcess(raw.data() + prev, ends[b] - prev);
                 prev = ends[b];
             }
-            z.erase(z.begin(), z.begin() + (long)used);
+            zoff += used;
             if (used == 0 && eof) {
-                if (!z.empty()) throw std::runtime_error(zlng_strerror(ZLNG_E_TRUNC));
+                if (z.size() != zoff) throw std::runtime_error(zlng_strerror(ZLNG_E_TRUNC));
                 break;
             }
-            if (z.empty() && eof) break;
+            if (z.size() == zoff && eof) break;
         }
     }
     if (handler) handler->OnDone();

@@ -105,3 +105,51 @@ def test_full_size_decode_round_trip(zl):
         back = d.decode(z, n)
     assert back.size == n
     assert hashlib.sha256(back.tobytes()).digest() == hashlib.sha256(x.tobytes()).digest()
+
+
+def test_good_blocks_are_reported_before_a_bad_one(zl, oracle):
+    """A corrupt sub-block in the second block of a prefix: the first block is decoded and reported (the reference writes every
+    block before it throws, src/libzling.cpp:306-420); the next call meets the bad block alone and returns its error; the
+    tables the context keeps are those at the start of the bad block, so a repaired stream continues correctly."""
+    import ctypes as C
+    from oracle_py import textgen
+    x = textgen(2 * zl.BLOCK + 100_000, 23)
+    z = oracle.encode(x, 0)
+    # end of block 0 = the only 0x00 flag byte that follows a whole number of sub-blocks; find it by walking the frame
+    p, ends = 0, []
+    while p < z.size:
+        if z[p] == 0:
+            ends.append(p + 1); p += 1; continue
+        p += 13 + int.from_bytes(z[p + 9:p + 13].tobytes(), "big")
+    bad = z.copy()
+    bad[ends[0] + 13: ends[0] + 13 + 257] = 0                       # block 1, first sub-block: no code for any symbol -> bad code1
+    L = zl.lib()
+    out = np.empty(3 * zl.BLOCK, np.uint8)
+    used, n = C.c_size_t(0), C.c_size_t(0)
+    bends = (C.c_size_t * 4)()
+    p8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    with zl.Stream(0, 0, False, 4) as d:
+        rc = L.zlng_decode_blocks(d._h, p8(bad), bad.size, C.byref(used), p8(out), out.size, C.byref(n), bends)
+        assert rc == 0 and used.value == ends[0] and n.value == zl.BLOCK and bends[0] == zl.BLOCK
+        assert np.array_equal(out[: zl.BLOCK], x[: zl.BLOCK])
+        rest = np.ascontiguousarray(bad[ends[0]:])
+        rc = L.zlng_decode_blocks(d._h, p8(rest), rest.size, C.byref(used), p8(out), out.size, C.byref(n), bends)
+        assert rc == -12 and n.value == 0                              # "invalid huffman stream. (bad code1)"
+        good = np.ascontiguousarray(z[ends[0]:])                       # the state survived the failed call
+        rc = L.zlng_decode_blocks(d._h, p8(good), good.size, C.byref(used), p8(out), out.size, C.byref(n), bends)
+        assert rc == 0 and np.array_equal(out[: n.value], x[zl.BLOCK:])
+
+
+def test_cli_decodes_an_unterminated_final_block(tmp_path, oracle):
+    """The reference's inner loop also ends at end of input (src/libzling.cpp:312-313): a last block that lacks its 0x00
+    terminator is still written.  Through the C++ API (tools/zling_demo)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "tools", "zling_demo")
+    x = corpus.get("text_64k")
+    z = oracle.encode(x, 0)
+    assert z[-1] == 0
+    q = subprocess.run([demo, "d"], input=z[:-1].tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert q.returncode == 0 and q.stdout == x.tobytes(), q.stderr[-300:]
+    q = subprocess.run([demo, "d"], input=z[:-40].tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert q.returncode != 0                                           # cut inside a payload: still an error
