@@ -286,11 +286,41 @@ def main():
             hot = enc.streams[-1].debug_fetch(8, 0, np.uint32, 256)
             if len(enc.parts) == 1 and args.level == 0:
                 res["rank_chain"] = rank_chain_line(x, args.level, int(hot.max()), stage.get("mtf_chain", 0.0))
+        if not args.no_cpu_baseline and world == 1 and len(enc.parts) == 1 and args.level == 0:
+            res["alt_host_rank_chains"] = alt_host_rank(args, local, nb, d_in, n, d_out, cap, d_state, d_state0, init_level, got)
         res["zlng_sha256_rank0"] = hashlib.sha256(got.tobytes()).hexdigest()
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def alt_host_rank(args, local, nb, d_in, n, d_out, cap, d_state, d_state0, init_level, want):
+    """The measured ALTERNATIVE the serial rank chain suggests (SURVEY 8(e) Option C), never the headline: the four longest
+    chains of the stream are walked by host threads (the library's opt-in ZLNG_HOST_RANK_CONTEXTS mode: literal runs over
+    PCIe, the reference's rank rule on host cores, ranks back) while the device walks all the others.  Same bytes."""
+    os.environ["ZLNG_HOST_RANK_CONTEXTS"] = "4"
+    try:
+        with zl.Stream(local, args.level, True, nb) as s:
+            def step():
+                d_state.copy_(d_state0); torch.cuda.synchronize()
+                s.set_state_device(d_state.data_ptr(), init_level)
+                return s.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                m = step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            st = dict(s.timings())
+            same = bool(m == want.size and np.array_equal(d_out[:m].cpu().numpy(), want))
+    finally:
+        del os.environ["ZLNG_HOST_RANK_CONTEXTS"]
+    return {"value": round(n / dt / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dt * 1e3, 3), "host_threads": 4, "identical_bytes": same,
+            "stage_ms": {k: round(v, 3) for k, v in st.items()},
+            "note": "NOT the product path and not `value`: opt-in mode in which host cores walk the 4 longest rank chains; reported "
+                    "because the chain is 6x faster on a host core than on a wavefront"}
 
 
 def bench_decode(args, world, rank, local):

@@ -146,6 +146,15 @@ int zlng_decode_blocks_device(zlng_ctx*, const void* d_in, size_t in_len, size_t
  * context's stream).  names[i] is a static string; returns the number of stages filled. */
 int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
 
+/* Environment read when a context is created (testing / measurement aids; none of them changes the bytes produced):
+ *   ZLNG_PARSER=serial|pipe       cross-check forms of the block parser (default: the single-wavefront speculative parser)
+ *   ZLNG_TOK_CAP=<words>          token words per block the pools start with (they grow once on overflow)
+ *   ZLNG_HOST_RANK_CONTEXTS=<k>   MEASURED ALTERNATIVE, off by default: the k longest rank chains of a call are walked
+ *                                 by host threads (literal runs over PCIe and back) while the device walks the others.
+ *                                 The product path is all-device; this mode exists because SURVEY 8(e) asks to choose by
+ *                                 measurement and bench.py reports it as a separate line.
+ *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py) */
+
 /* The hipStream_t the context launches on (as void*), for callers that need to order work. */
 void* zlng_stream(zlng_ctx*);
 

@@ -391,6 +391,11 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
 __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     const uint32_t ctx = blockIdx.x;
     const uint32_t lane = threadIdx.x;
+    if (a.skip && a.skip[ctx]) {                                       // ranked elsewhere: only tell the replay to keep off
+        const uint32_t tiles = (a.ctx_total[ctx] + 63u) >> 6;
+        for (uint32_t t = lane; t < tiles; t += 64) a.tile_kk[(a.ctx_off[ctx] >> 6) + t] = 0;
+        return;
+    }
     uint8_t* st = a.state + ctx * 256;
     uint32_t t0 = st[lane], t1 = st[64 + lane], t2 = st[128 + lane], t3 = st[192 + lane];
 

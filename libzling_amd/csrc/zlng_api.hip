@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/zlng.h"
@@ -74,6 +75,15 @@ struct zlng_ctx {
     uint8_t*  d_lit_byte = nullptr;
     uint8_t*  d_snap = nullptr;       // rank stage: table snapshots per 64-literal tile
     uint8_t*  d_tile_kk = nullptr;
+    // Measured ALTERNATIVE, off by default (ZLNG_HOST_RANK_CONTEXTS=k): the k longest rank chains of a
+    // call are walked by host threads instead of by k_mtf_dense, overlapped with the device's other chains.  The product
+    // path is all-device; bench.py reports this mode as a separate, labelled line and never as `value`.
+    int       host_rank_contexts = 0;
+    uint8_t*  d_skip = nullptr;       // [256] contexts left to the host
+    uint8_t*  h_pinned = nullptr;     // page-locked staging for their literal runs
+    size_t    h_pinned_cap = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t  ev2 = nullptr;
     // decode pools
     DecSub*   d_subs = nullptr;
     DecBlock* d_blocks = nullptr;
@@ -202,18 +212,88 @@ HuffArgs huff_args(zlng_ctx* c, uint32_t nb, uint32_t blk0, uint8_t* d_out, size
                     c->d_sub_off, c->d_blk_end, c->d_summary, overflow_flag(c), d_out, (uint64_t)out_cap};
 }
 
+// ---- measured alternative: the longest chains on host cores (ZLNG_HOST_RANK_CONTEXTS, off by default) -------------------
+// ZlingMTFEncoder::Encode (src/libzling_lz.cpp:112-117) on one context's dense literal run, ranks in place.
+void mtf_chain_host(uint8_t table[256], uint8_t* lits, size_t n) {
+    uint8_t index[256], nxt[256];
+    for (int i = 0; i < 256; i++) { index[table[i]] = (uint8_t)i; nxt[i] = (uint8_t)mtf_next((uint32_t)i); }
+    for (size_t j = 0; j < n; j++) {
+        const uint8_t ch = lits[j], i = index[ch], nx = nxt[i], d = table[nx];
+        table[nx] = ch; table[i] = d; index[ch] = nx; index[d] = i;
+        lits[j] = i;
+    }
+}
+
+int rank_longest_chains_on_host(zlng_ctx* c, MtfArgs& ma, bool single) {
+    uint32_t total[256], off[256];
+    CTX_HIP(hipMemcpyAsync(total, c->d_ctx_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipMemcpyAsync(off, c->d_ctx_off, sizeof off, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    // the k longest chains, if they are long enough to be worth two PCIe copies
+    std::vector<int> pick;
+    uint8_t skip[256] = {0};
+    for (int k = 0; k < c->host_rank_contexts; k++) {
+        int best = -1;
+        for (int x = 0; x < 256; x++) if (!skip[x] && total[x] >= (1u << 18) && (best < 0 || total[x] > total[best])) best = x;
+        if (best < 0) break;
+        skip[best] = 1;
+        pick.push_back(best);
+    }
+    size_t need = 0;
+    for (int x : pick) need += ((size_t)total[x] + 63) & ~(size_t)63;
+    if (need > c->h_pinned_cap) {
+        if (c->h_pinned) hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr; c->h_pinned_cap = 0;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, need + (need >> 2) + 4096, hipHostMallocDefault) != hipSuccess) return ZLNG_E_NOMEM;
+        c->h_pinned = static_cast<uint8_t*>(p); c->h_pinned_cap = need + (need >> 2) + 4096;
+    }
+    CTX_HIP(hipMemcpyAsync(c->d_skip, skip, 256, hipMemcpyHostToDevice, c->stream));
+    CTX_HIP(hipEventRecord(c->ev2, c->stream));                       // partition done, skip list in place
+    ma.skip = c->d_skip;
+    launch_mtf_chain(ma, c->stream);                                  // the device walks every other chain meanwhile
+    if (single) timer_mark(c, "mtf_chain");
+    // second stream: runs out, host chains, ranks and tables back
+    CTX_HIP(hipStreamWaitEvent(c->stream2, c->ev2, 0));
+    std::vector<uint8_t> tables(pick.size() * 256);
+    size_t pos = 0;
+    std::vector<size_t> at(pick.size());
+    for (size_t k = 0; k < pick.size(); k++) {
+        at[k] = pos;
+        CTX_HIP(hipMemcpyAsync(c->h_pinned + pos, c->d_lit_byte + off[pick[k]], total[pick[k]], hipMemcpyDeviceToHost, c->stream2));
+        CTX_HIP(hipMemcpyAsync(tables.data() + 256 * k, c->d_mtf + 256 * pick[k], 256, hipMemcpyDeviceToHost, c->stream2));
+        pos += ((size_t)total[pick[k]] + 63) & ~(size_t)63;
+    }
+    CTX_HIP(hipStreamSynchronize(c->stream2));
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < pick.size(); k++)
+        th.emplace_back(mtf_chain_host, tables.data() + 256 * k, c->h_pinned + at[k], (size_t)total[pick[k]]);
+    for (auto& t : th) t.join();
+    for (size_t k = 0; k < pick.size(); k++) {
+        CTX_HIP(hipMemcpyAsync(c->d_lit_byte + off[pick[k]], c->h_pinned + at[k], total[pick[k]], hipMemcpyHostToDevice, c->stream2));
+        CTX_HIP(hipMemcpyAsync(c->d_mtf + 256 * pick[k], tables.data() + 256 * k, 256, hipMemcpyHostToDevice, c->stream2));
+    }
+    CTX_HIP(hipStreamSynchronize(c->stream2));                        // (tables is a local: the copies must have read it)
+    return ZLNG_OK;                                                   // the caller's next launch on c->stream follows k_mtf_dense
+}
+
 // Rank (group by group from group g0, whose entry tables are in d_mtf), histogram and lengths of blocks [g0 * G, nb).
 int run_back(zlng_ctx* c, uint32_t nb, uint32_t g0, uint8_t* d_out, size_t out_cap) {
     const uint32_t G = rank_group_blocks(c, nb);
     for (uint32_t b = g0 * G, g = g0; b < nb; b += G, g++) {
         const uint32_t n = std::min(G, nb - b);
         MtfArgs ma{c->d_tok + (size_t)b * c->tok_cap, c->d_ntok + b, n, c->tok_cap, c->d_mtf, c->d_tile_base, c->d_tile_hist,
-                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk};
+                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, nullptr};
         const bool single = G >= nb;                 // one group (always at level 0): time the serial chain by itself
         launch_lit_partition(ma, c->stream);
         if (single) timer_mark(c, "lit_partition");
-        launch_mtf_chain(ma, c->stream);
-        if (single) timer_mark(c, "mtf_chain");
+        if (c->host_rank_contexts > 0) {
+            const int rc = rank_longest_chains_on_host(c, ma, single);
+            if (rc != ZLNG_OK) return rc;
+        } else {
+            launch_mtf_chain(ma, c->stream);
+            if (single) timer_mark(c, "mtf_chain");
+        }
         launch_mtf_finish(ma, c->stream);
         if (b + G < nb)        // tables at the start of the next group
             CTX_HIP(hipMemcpyAsync(c->d_mtf_snap + (size_t)(g + 1) * ZLNG_MTF_STATE, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
@@ -432,6 +512,13 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
         c->h_olen.resize(nsubs);
         c->h_cuts.resize(nsubs);
         c->h_blk_end.resize(nb);
+        const char* hr = getenv("ZLNG_HOST_RANK_CONTEXTS");
+        c->host_rank_contexts = hr ? std::min(8, std::max(0, atoi(hr))) : 0;
+        if (c->host_rank_contexts > 0) {
+            if ((rc = dev_alloc(c, &c->d_skip, 256))) return fail(rc);
+            if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess)
+                return fail(ZLNG_E_DEVICE);
+        }
         const char* pf = getenv("ZLNG_PROFILE");
         if (pf && pf[0] == '1') {
             if ((rc = dev_alloc(c, &c->d_dbg, nb * kDbgSlots))) return fail(rc);
@@ -450,8 +537,11 @@ void zlng_destroy(zlng_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
                     c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_snap, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring, c->d_tile_base, c->d_tile_hist,
-                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk};
+                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, c->d_skip};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->ev2) hipEventDestroy(c->ev2);
     for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -42,6 +42,7 @@ struct MtfArgs {
     uint8_t*        lit_byte;  // dense literal bytes, context-major, stream order inside a context; ranks in place
     uint8_t*        snap;      // table front (64 B) at the start of every 64-literal tile of lit_byte (same indexing)
     uint8_t*        tile_kk;   // per tile: literals whose ranks k_mtf_replay computes from the snapshot (0 = none)
+    const uint8_t*  skip;      // optional [256]: contexts k_mtf_dense leaves alone (the measured host-chain alternative, zlng_api.hip)
 };
 void launch_lit_partition(const MtfArgs& a, hipStream_t s);   // literals -> one dense run per context
 void launch_mtf_chain(const MtfArgs& a, hipStream_t s);       // k_mtf_dense: the serial chains

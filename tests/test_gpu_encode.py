@@ -327,12 +327,38 @@ import libzling_amd as zl
 from oracle_py import Oracle, textgen
 n = 2 * zl.BLOCK + 300_000 if %r == "pipe" else 700_000
 x = textgen(n, 17)
-x[n // 2: n // 2 + 400_000] = np.random.Generator(np.random.PCG64(3)).integers(0, 256, 400_000, dtype=np.uint8)
+x[n // 2: n // 2 + 300_000] = np.random.Generator(np.random.PCG64(3)).integers(0, 256, 300_000, dtype=np.uint8)
 o = Oracle()
 for lv in (0, 4):
     assert np.array_equal(zl.encode(x, lv), o.encode(x, lv)), lv
 print("ok")
 ''' % (os.path.dirname(G.rstrip("/")).rsplit("/tests", 1)[0], os.path.join(os.path.dirname(G.rstrip("/")).rsplit("/tests", 1)[0], "oracle"), parser)
     env = dict(os.environ, ZLNG_PARSER=parser)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_host_rank_chain_alternative_is_bit_exact():
+    """ZLNG_HOST_RANK_CONTEXTS (opt-in, measured alternative: the longest rank chains on host threads, the rest on the device):
+    same bytes as the oracle over several blocks and two calls of one stream, at e0 and e4.  Own process: the mode is chosen
+    when the context is created."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r]
+import libzling_amd as zl
+from oracle_py import Oracle, textgen
+x = textgen(3 * zl.BLOCK + 500_000, 29)
+o = Oracle()
+for lv in (0, 4):
+    want = o.encode(x, lv)
+    with zl.Stream(0, lv, True, 2) as s:
+        got = np.concatenate([s.encode(x[: 2 * zl.BLOCK]), s.encode(x[2 * zl.BLOCK:])])
+    assert np.array_equal(got, want), lv
+print("ok")
+''' % (root, os.path.join(root, "oracle"))
+    env = dict(os.environ, ZLNG_HOST_RANK_CONTEXTS="3")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
