@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
     ZLNG_MTF_S_STEP(PK, 0, A, Z) ZLNG_MTF_S_STEP(PK, 1, B, A) ZLNG_MTF_S_STEP(PK, 2, C, B) ZLNG_MTF_S_STEP(PK, 3, D, C)
 #define ZLNG_MTF_S_COLD(PK, A, B, C, D, N)                                                                      \
     ZLNG_MTF_S_SLOW(PK, 0, A, B) ZLNG_MTF_S_SLOW(PK, 1, B, C) ZLNG_MTF_S_SLOW(PK, 2, C, D) ZLNG_MTF_S_SLOW(PK, 3, D, N)
-#define ZLNG_MTF_TILE_S()                                                                                       \
+#define ZLNG_MTF_TILE_S(PKIN, NXTOUT)                                                                           \
     asm volatile(                                                                                               \
         "s_load_dwordx16 %[nxt], %[ptr], 0x40\n\t"                                                              \
         "s_cmp_eq_u32 0, 0\n\t"                                                                                 \
@@ -381,11 +381,11 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
         "9:\n\t"                                                                                                \
         "s_waitcnt lgkmcnt(0)"                                                                                  \
         : [t0] "+v"(t0), [up] "+v"(up), [m1] "=&s"(m1_), [i] "=&s"(i_), [nx] "=&s"(nx_),                        \
-          [d] "=&s"(d_), [da] "=&s"(da_), [db] "=&s"(db_), [lv] "=&s"(lv_), [nxt] "=&s"(nxt)                    \
-        : [ptr] "s"(tile_ptr), [p0] "s"(pk[0]), [p1] "s"(pk[1]), [p2] "s"(pk[2]), [p3] "s"(pk[3]),              \
-          [p4] "s"(pk[4]), [p5] "s"(pk[5]), [p6] "s"(pk[6]), [p7] "s"(pk[7]), [p8] "s"(pk[8]), [p9] "s"(pk[9]), \
-          [p10] "s"(pk[10]), [p11] "s"(pk[11]), [p12] "s"(pk[12]), [p13] "s"(pk[13]), [p14] "s"(pk[14]),        \
-          [p15] "s"(pk[15])                                                                                     \
+          [d] "=&s"(d_), [da] "=&s"(da_), [db] "=&s"(db_), [lv] "=&s"(lv_), [nxt] "=&s"(NXTOUT)                    \
+        : [ptr] "s"(tile_ptr), [p0] "s"(PKIN[0]), [p1] "s"(PKIN[1]), [p2] "s"(PKIN[2]), [p3] "s"(PKIN[3]),              \
+          [p4] "s"(PKIN[4]), [p5] "s"(PKIN[5]), [p6] "s"(PKIN[6]), [p7] "s"(PKIN[7]), [p8] "s"(PKIN[8]), [p9] "s"(PKIN[9]), \
+          [p10] "s"(PKIN[10]), [p11] "s"(PKIN[11]), [p12] "s"(PKIN[12]), [p13] "s"(PKIN[13]), [p14] "s"(PKIN[14]),        \
+          [p15] "s"(PKIN[15])                                                                                     \
         : "vcc", "scc", "s98", "s99", "m0")
 
 __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
@@ -421,38 +421,44 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     typedef uint32_t Tile16 __attribute__((ext_vector_type(16)));
     Tile16 pk;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pk) : "s"(run));     // first tile
-    for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t ranks = 0xFFFFFFFFu;
-        if (base + 64 <= n) {
-            const uint8_t* tile_ptr = run + base;
-            Tile16 nxt;
-            uint32_t i_, nx_, d_, da_, db_, lv_;
-            uint64_t m1_;
-            snap[base + lane] = (uint8_t)t0;                             // table front at the start of the tile, for k_mtf_replay
-            ZLNG_MTF_TILE_S();
-            pk = nxt;
-            uint32_t kk = 64;                                            // literals of this tile whose ranks the replay computes
-            if (__builtin_expect(lv_ != 0, 0)) {                         // literal lv_ - 1 has rank >= 64: the statement stopped there
-#define RANKSTORE(I, K) wrl(ranks, I, K)
-                kk = lv_ - 1;
-                const uint32_t v = run[base + lane];
-                const uint32_t r = slow_step(rdl(v, kk));
-                wrl(ranks, r, kk);
-                for (uint32_t k = kk + 1; k < 64u; k++) ZLNG_MTF_STEP(k)
-#undef RANKSTORE
-                if (lane >= kk) run[base + lane] = (uint8_t)ranks;       // lanes below kk keep their literal for the replay
-            }
-            if (lane == 0) tile_kk[base >> 6] = (uint8_t)kk;
-        } else {
-#define RANKSTORE(I, K) wrl(ranks, I, K)
-            const uint32_t cnt = n - base;
-            const uint32_t v = lane < cnt ? (uint32_t)run[base + lane] : 0u;
-            for (uint32_t k = 0; k < cnt; k++) ZLNG_MTF_STEP(k)
-#undef RANKSTORE
-            if (lane < cnt) run[base + lane] = (uint8_t)ranks;
-            if (lane == 0) tile_kk[base >> 6] = 0;
-        }
+    // One full tile in the state-only form: consumes the 64 literals in PKIN, leaves the next tile's in NXTOUT.  tile_kk is
+    // pre-set to 64 ("the replay ranks the whole tile", launch_lit_partition) and only written when a tile differs.
+#define ZLNG_MTF_FULL_TILE(BASE, PKIN, NXTOUT)                                                                     \
+    {                                                                                                              \
+        const uint8_t* tile_ptr = run + (BASE);                                                                    \
+        uint32_t i_, nx_, d_, da_, db_, lv_;                                                                       \
+        uint64_t m1_;                                                                                              \
+        snap[(BASE) + lane] = (uint8_t)t0;          /* table front at the start of the tile, for k_mtf_replay */   \
+        ZLNG_MTF_TILE_S(PKIN, NXTOUT);                                                                             \
+        if (__builtin_expect(lv_ != 0, 0)) {        /* literal lv_ - 1 has rank >= 64: the statement stopped there */ \
+            uint32_t ranks = 0;                                                                                    \
+            const uint32_t kk = lv_ - 1;                                                                           \
+            const uint32_t v = run[(BASE) + lane];                                                                 \
+            const uint32_t r = slow_step(rdl(v, kk));                                                              \
+            wrl(ranks, r, kk);                                                                                     \
+            for (uint32_t k = kk + 1; k < 64u; k++) ZLNG_MTF_STEP(k)                                               \
+            if (lane >= kk) run[(BASE) + lane] = (uint8_t)ranks;   /* lanes below kk keep their literal for the replay */ \
+            if (lane == 0) tile_kk[(BASE) >> 6] = (uint8_t)kk;                                                     \
+        }                                                                                                          \
     }
+#define RANKSTORE(I, K) wrl(ranks, I, K)
+    uint32_t base = 0;
+    Tile16 pk2;
+    for (; base + 128 <= n; base += 128) {           // two tiles per turn: the literal registers ping-pong, no copy
+        ZLNG_MTF_FULL_TILE(base, pk, pk2)
+        ZLNG_MTF_FULL_TILE(base + 64, pk2, pk)
+    }
+    if (base + 64 <= n) { ZLNG_MTF_FULL_TILE(base, pk, pk2) base += 64; }
+    if (base < n) {                                  // the run's last, partial tile: recording form, nothing left to the replay
+        uint32_t ranks = 0xFFFFFFFFu;
+        const uint32_t cnt = n - base;
+        const uint32_t v = lane < cnt ? (uint32_t)run[base + lane] : 0u;
+        for (uint32_t k = 0; k < cnt; k++) ZLNG_MTF_STEP(k)
+        if (lane < cnt) run[base + lane] = (uint8_t)ranks;
+        if (lane == 0) tile_kk[base >> 6] = 0;
+    }
+#undef RANKSTORE
+#undef ZLNG_MTF_FULL_TILE
     st[lane] = (uint8_t)t0; st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
 }
 
@@ -481,6 +487,7 @@ __global__ __launch_bounds__(256) void k_mtf_replay(MtfArgs a) {
 // The stage in three launches, so the host can time the serial chain (the kernel the roofline line is about) by itself.
 void launch_lit_partition(const MtfArgs& a, hipStream_t s) {
     const dim3 tiles((unsigned)(a.tok_cap / kLitTile), a.nblocks);
+    (void)hipMemsetAsync(a.tile_kk, 64, ((size_t)a.nblocks * a.tok_cap + 256 * 64) / 64, s);   // "the replay ranks the whole tile"
     hipLaunchKernelGGL(k_lit_tile_base, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_lit_tiles<kModeHist>, tiles, dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_lit_scan, dim3(256), dim3(256), 0, s, a);
