@@ -49,12 +49,16 @@ KERNEL_OF_STAGE = {"rolz_parse": "k_rolz_parse_wave", "mtf_rank": "k_mtf_dense",
                    "histogram": "k_histogram", "huff_decode": "k_huff_decode", "rolz_decode": "k_rolz_decode", "frame_walk": "k_frame_walk"}
 
 
+ENCODE_KERNEL_SOURCES = ("zlng_common.h", "zlng_kernels.h", "rolz_dev.h", "rolz_parse.hip", "mtf_rank.hip", "huffman.hip")
+
+
 def kernel_source_sha():
-    """Identity of the kernels a profile was taken on (the GPU box has no .git): SHA-256 over the csrc sources."""
+    """Identity of the encode kernels a profile was taken on (the GPU box has no .git): SHA-256 over their sources (the
+    host-side ABI code, the decode kernels and the experimental parser are not part of what the profile measures)."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.h"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in ENCODE_KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "libzling_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 

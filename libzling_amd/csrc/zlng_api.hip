@@ -361,6 +361,7 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
     if (!d_in || !d_out || ((uintptr_t)d_out & 3)) return ZLNG_E_ARG;
     const uint32_t nb = blocks_of(in_len);
     if (nb > c->max_blocks) return ZLNG_E_ARG;
+    if (!c->d_tok || !c->d_lit_byte || !c->d_snap) return ZLNG_E_NOMEM;      // an earlier pool growth ran out of HBM
     CTX_HIP(hipSetDevice(c->device));
 
     const int entry_level = c->current_level;

@@ -9,12 +9,15 @@ import glob, hashlib, json, os, re, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+ENCODE_KERNEL_SOURCES = ("zlng_common.h", "zlng_kernels.h", "rolz_dev.h", "rolz_parse.hip", "mtf_rank.hip", "huffman.hip")
+
+
 def kernel_source_sha():
-    """Same identity bench.py computes: the profile is only quoted for the kernel sources it was taken on."""
+    """Same identity bench.py computes: the profile is only quoted for the encode-kernel sources it was taken on."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "libzling_amd", "csrc", "*.h"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in ENCODE_KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "libzling_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
