@@ -134,6 +134,14 @@ constexpr uint32_t kTyNone = 0, kTyLit = 1, kTyW0 = 2, kTyW1 = 3, kTyMatch = 4;
 
 struct Quad { uint32_t a, b, c, d; };
 __device__ __forceinline__ Quad ld128u(const uint8_t* p) { Quad q; __builtin_memcpy(&q, p, 16); return q; }
+// Index of the first differing byte of two 16-byte groups (16 = equal).
+__device__ __forceinline__ uint32_t first_diff16(const Quad x, const Quad y) {
+    const unsigned long long lo = (unsigned long long)(x.a ^ y.a) | ((unsigned long long)(x.b ^ y.b) << 32);
+    const unsigned long long hi = (unsigned long long)(x.c ^ y.c) | ((unsigned long long)(x.d ^ y.d) << 32);
+    const uint32_t dl = lo ? ((uint32_t)__ffsll((long long)lo) - 1u) >> 3 : 8u;
+    const uint32_t dh = hi ? ((uint32_t)__ffsll((long long)hi) - 1u) >> 3 : 8u;
+    return lo ? dl : 8u + dh;
+}
 
 // byte-wise common prefix of a and b, capped at 259, given that it is going to be compared with
 // a threshold >= 3: returns 0 when the first four bytes differ (GetCommonLength, src/libzling_lz.cpp:66-89).
@@ -145,13 +153,12 @@ __device__ __forceinline__ int common_len_q(const uint8_t* a, const uint8_t* b, 
     x = qa.c ^ qb.c; if (x) return 8 + (__ffs((int)x) - 1) / 8;
     x = qa.d ^ qb.d; if (x) return 12 + (__ffs((int)x) - 1) / 8;
     int n = 16;
-    while (n + 4 <= kMatchMax) {
-        x = ld32u(a + n) ^ ld32u(b + n);
-        if (x) return n + (__ffs((int)x) - 1) / 8;
-        n += 4;
+    while (n < kMatchMax) {
+        const uint32_t d = first_diff16(ld128u(a + n), ld128u(b + n));
+        n += (int)d;
+        if (d < 16u) break;
     }
-    while (n < kMatchMax && a[n] == b[n]) n++;
-    return n;
+    return n < kMatchMax ? n : kMatchMax;
 }
 
 // Speculative evaluation of one position as a token start (phase 1 of the parser, also run ahead of
@@ -167,6 +174,12 @@ struct Spec {
     // alone, the lazy probe's source offset (bit 31: probe chain non-empty), the 16 input bytes at the position
     uint32_t len0, lsrc1;
     Quad qa;
+    // level 0 with deferred tails (speculate_l0<true>): a lane whose compare against a chain node reached 16 bytes is
+    // "open" -- its lengths are lower bounds and its lazy probe has not been evaluated -- until the parser finishes it
+    // (only token starts are ever finished).  off0 / off1: sources of the two nodes; olen: len0 | len1 << 8 |
+    // long0 << 16 | long1 << 17 | node 1 exists << 18 | node 1's ring slot << 19.
+    uint32_t off0, off1, olen;
+    bool open;
 };
 
 __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
@@ -176,18 +189,22 @@ __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      /
     len = x1 ? 4u + ((uint32_t)__ffs((int)x1) - 1u) / 8u : len;
     return x0 ? 0u : len;
 }
-__device__ __forceinline__ uint32_t lcp_tail(const uint8_t* a, const uint8_t* b, bool active) {   // continue an LCP of 16
+// Continue an LCP of 16 up to kMatchMax, 32 bytes per memory round trip: a
+// 259-byte match costs 8 dependent loads, not 63 (long matches are the common
+// case on source code and markup, where every lane of a round sits inside one).
+__device__ __forceinline__ uint32_t lcp_tail(const uint8_t* a, const uint8_t* b, bool active) {
     uint32_t n = 16;
     while (__any(active)) {
         if (active) {
-            if (n + 4 <= (uint32_t)kMatchMax) {
-                const uint32_t x = ld32u(a + n) ^ ld32u(b + n);
-                if (x) { n += ((uint32_t)__ffs((int)x) - 1u) / 8u; active = false; } else n += 4;
-            } else if (n < (uint32_t)kMatchMax && a[n] == b[n]) n++;
-            else active = false;
+            const Quad a0 = ld128u(a + n), b0 = ld128u(b + n);
+            const Quad a1 = ld128u(a + n + 16), b1 = ld128u(b + n + 16);
+            uint32_t d = first_diff16(a0, b0);
+            if (d == 16u) d += first_diff16(a1, b1);
+            n += d;
+            if (d < 32u || n >= (uint32_t)kMatchMax) active = false;
         }
     }
-    return n;
+    return n < (uint32_t)kMatchMax ? n : (uint32_t)kMatchMax;
 }
 
 
@@ -276,6 +293,37 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
 // a handful of exec-mask instructions, and one wavefront issues an instruction only every few cycles, so on
 // the level the benchmark runs the generic form spends most of phase 1 on control flow rather than on the
 // five dependent memory round trips.  Only the >16-byte tail of a long match keeps a (wave-uniform) loop.
+// Two LCP tails against the same position in one loop (level 0 compares the two newest chain nodes): both pairs
+// are at the same byte count while they are alive, so the position side is loaded once and a round in a
+// long-match region pays 8 round trips, not 16.
+__device__ __forceinline__ void lcp_tail2(const uint8_t* a, const uint8_t* b, const uint8_t* c, bool act0, bool act1,
+                                          uint32_t& r0, uint32_t& r1) {
+    uint32_t n = 16;
+    r0 = 16; r1 = 16;
+    while (__any(act0 || act1)) {
+        if (act0 || act1) {
+            const uint8_t* pb = act0 ? b : a;
+            const uint8_t* pc = act1 ? c : a;
+            const Quad a0 = ld128u(a + n), a1 = ld128u(a + n + 16);
+            const Quad b0 = ld128u(pb + n), b1 = ld128u(pb + n + 16);
+            const Quad c0 = ld128u(pc + n), c1 = ld128u(pc + n + 16);
+            uint32_t d0 = first_diff16(a0, b0);
+            if (d0 == 16u) d0 += first_diff16(a1, b1);
+            uint32_t d1 = first_diff16(a0, c0);
+            if (d1 == 16u) d1 += first_diff16(a1, c1);
+            if (act0) { r0 = n + d0; act0 = d0 == 32u && r0 < (uint32_t)kMatchMax; }
+            if (act1) { r1 = n + d1; act1 = d1 == 32u && r1 < (uint32_t)kMatchMax; }
+            n += 32;
+        }
+    }
+    r0 = r0 < (uint32_t)kMatchMax ? r0 : (uint32_t)kMatchMax;
+    r1 = r1 < (uint32_t)kMatchMax ? r1 : (uint32_t)kMatchMax;
+}
+
+constexpr uint32_t kOpenAt = 16;                     // deferred tails: bytes compared in phase 1 before a lane is left open.  48 (one 32-byte step
+                                                     // for every long lane in phase 1) was measured too: real text -2 %, the benchmark text +2 %
+
+template <bool kDefer = false>
 __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t risk_dist, int pos,
                                              const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t w4 = qa.a;
@@ -297,26 +345,54 @@ __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8
     const uint32_t nov = B.offset[nx & (kRing - 1)];
     uint32_t len0 = cmp0 ? lcp16(qa, q0) : 0u;
     const bool long0 = cmp0 && len0 == 16u;
-    if (__any(long0)) { const uint32_t t = lcp_tail(buf + pos, buf + off0, long0); len0 = long0 ? t : len0; }
-    uint32_t maxlen = kMatchMin - 1, maxnode = 0;
-    if (len0 > maxlen) { maxlen = len0; maxnode = node0; }
-    // chain continues to node 1?  (src/libzling_lz.cpp:255-266)
-    const bool has1 = has0 && maxlen != (uint32_t)kMatchMax && nx != 65535u;
+    // chain continues to node 1?  (src/libzling_lz.cpp:255-266)  Node 1 is compared before node 0's length is
+    // final: it only matters when that length is below kMatchMax, and a node-1 length can never beat kMatchMax.
+    const bool has1s = has0 && nx != 65535u;
     const uint32_t off1 = nov & 0xFFFFFF;
-    const bool go1 = has1 && !(off0 <= off1);
+    const bool go1 = has1s && !(off0 <= off1);
     // round trip 4: compare bytes of node 1
     const bool cmp1 = go1 && (nov >> 24) == chk;
     const Quad q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
     uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
     const bool long1 = cmp1 && len1 == 16u;
-    if (__any(long1)) { const uint32_t t = lcp_tail(buf + pos, buf + off1, long1); len1 = long1 ? t : len1; }
-    if (len1 > maxlen) { maxlen = len1; maxnode = nx; }
+    bool open = false;
+    if (kDefer) {
+        bool o0 = long0, o1 = long1;
+        if (kOpenAt > 16u && __any(long0 || long1)) {            // bytes 16 .. 47 of every long lane, here and now
+            const uint8_t* pa = buf + pos;
+            const uint8_t* pb = long0 ? buf + off0 : pa;
+            const uint8_t* pc = long1 ? buf + off1 : pa;
+            const Quad a0 = ld128u(pa + 16), a1 = ld128u(pa + 32);
+            const Quad b0 = ld128u(pb + 16), b1 = ld128u(pb + 32);
+            const Quad c0 = ld128u(pc + 16), c1 = ld128u(pc + 32);
+            uint32_t d0 = first_diff16(a0, b0);
+            if (d0 == 16u) d0 += first_diff16(a1, b1);
+            uint32_t d1 = first_diff16(a0, c0);
+            if (d1 == 16u) d1 += first_diff16(a1, c1);
+            if (long0) { len0 = 16u + d0; o0 = d0 == 32u; }
+            if (long1) { len1 = 16u + d1; o1 = d1 == 32u; }
+        }
+        open = o0 || o1;
+        S.off0 = off0; S.off1 = off1; S.open = open;
+        S.olen = len0 | len1 << 8 | (o0 ? 1u << 16 : 0u) | (o1 ? 1u << 17 : 0u) | (has1s ? 1u << 18 : 0u) | (nx & (kRing - 1)) << 19;
+    } else if (__any(long0 || long1)) {
+        uint32_t t0, t1;
+        lcp_tail2(buf + pos, buf + off0, buf + off1, long0, long1, t0, t1);
+        len0 = long0 ? t0 : len0;
+        len1 = long1 ? t1 : len1;
+    }
+    uint32_t maxlen = kMatchMin - 1, maxnode = 0;
+    if (len0 > maxlen) { maxlen = len0; maxnode = node0; }
+    const bool has1 = has1s && maxlen != (uint32_t)kMatchMax;
+    if (has1 && len1 > maxlen) { maxlen = len1; maxnode = nx; }
     uint32_t dmin = kRing - 1;
     dmin = has0 ? min(dmin, ring_dist(node0, head0)) : dmin;
     dmin = has1 ? min(dmin, ring_dist(nx, head0)) : dmin;          // its offset was read for the chain-end test
     uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
     // round trip 5: the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1)
-    const bool lz1 = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
+    // (an open lane's probe waits for its final length; dmin above may count node 1 although node 0 turns out to
+    //  have the maximum length: a conflict flagged for nothing only costs an exact replay)
+    const bool lz1 = !open && maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
     const uint32_t m = lz1 ? maxlen - 3u : 0u;
     const uint32_t probe = ld32u(buf + ((uint32_t)pos + 1u + m));
     const uint32_t srcw = ld32u(buf + ((lz1 && hasl) ? (lov1 & 0xFFFFFF) + m : (uint32_t)pos));

@@ -194,9 +194,16 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                 const uint32_t hp = hash_of(qap.a);
                 Spec S;
                 const uint32_t pctx = wpp >> 24, pl1 = qap.a & 0xFF, pl2 = (qap.a >> 8) & 0xFF;
-                if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) speculate_l0(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) speculate_l0<true>(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 else speculate(S, dict, buf, heads[pctx], heads[pl1], heads[pl2], kRiskDist, pos, pcfg, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
+                // an open lane's tail is settled by one dependent round trip in phase 2 if it is a token start: pull
+                // the next line of both sources towards L2 now (the 16 compared bytes already brought the first)
+                if (S.open) {
+                    const uint32_t t0 = ld32u(buf + ((S.olen >> 16) & 1u ? S.off0 + 128u : (uint32_t)pos));
+                    const uint32_t t1 = ld32u(buf + ((S.olen >> 17) & 1u ? S.off1 + 128u : (uint32_t)pos));
+                    asm volatile("" :: "v"(t0), "v"(t1));
+                }
             }
             done_to = start + 64;
         }
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     int q = 0, nsub = 0;
     bool overflow = false;
     unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
-    unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0;
+    unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0, n_fin = 0, c_fin = 0, c_finw = 0;
     const bool prof = kProf && a.dbg != nullptr;
 
     while (q < ilen && !overflow) {                  // ---- one sub-block (one EncodeImpl call)
@@ -263,6 +270,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             S.lkix1 = S.lkix2 = S.lctx1 = S.lctx2 = 0; S.lz1 = S.lz2 = false;
             S.ld1 = S.ld2 = kRing - 1;
             S.len0 = 0; S.lsrc1 = 0; S.qa = Quad{0, 0, 0, 0};
+            S.off0 = S.off1 = S.olen = 0; S.open = false;
             const uint32_t kix_w = canm ? kix : (uint32_t)kKeyTab, ctx_w = canm ? ctx : 256u;
             atomicOr(&keytab[kix_w], lane_bit);
             atomicOr(&ctxtab[ctx_w], lane_bit);
@@ -270,19 +278,23 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             // without room for a match (the last 275 bytes of the block) reads at most 354 bytes past the block -- the
             // next block's text or the boundary's 512 readable bytes -- and everything derived from its result is
             // gated by canm below.
-            if (level0) speculate_l0(S, dict, buf, heads[ctx], heads[w4 & 0xFF], kRiskDist, pos, qtext, ctx, hc, chk);
+            if (level0) speculate_l0<true>(S, dict, buf, heads[ctx], heads[w4 & 0xFF], kRiskDist, pos, qtext, ctx, hc, chk);
             else if (canm) speculate(S, dict, buf, heads[ctx], heads[w4 & 0xFF], heads[(w4 >> 8) & 0xFF], kRiskDist, pos, cfg, qtext, ctx, hc, chk);
-            const uint32_t sp = (level0 && !canm) ? (uint32_t)(kMatchMin - 1) : S.sp;
+            uint32_t sp = (level0 && !canm) ? (uint32_t)(kMatchMin - 1) : S.sp;
             const uint32_t node0 = S.node0, head0 = S.head0, dmin = S.dmin;
             const uint32_t lkix1 = S.lkix1, lkix2 = S.lkix2, lctx1 = S.lctx1, lctx2 = S.lctx2;
             const bool lz1 = S.lz1, lz2 = S.lz2;
             if (prof) t1 = __builtin_readcyclecounter();
             // speculative token of this lane: match (if not vetoed by its speculative lazy probes) or literal
-            const uint32_t spec_len = sp & kSpLenMask;
+            // (level 0: a lane whose compare ran to 16 bytes is "open": length, node and lazy veto are settled by
+            //  finish_open below, and only if the lane turns out to be a token start)
+            uint32_t spec_len = sp & kSpLenMask;
             const bool spec_veto = ((sp & kSpVeto1) != 0) || (cfg.lazy2 > 0 && (sp & kSpVeto2) != 0);
-            const bool spec_match = canm && spec_len >= (uint32_t)kMatchMin && !(spec_len < (uint32_t)kLazyLimit && spec_veto);
-            const uint32_t tlen = spec_match ? spec_len : 1u;
-            const unsigned long long match_lanes = __ballot(spec_match);
+            bool spec_match = canm && spec_len >= (uint32_t)kMatchMin && !(spec_len < (uint32_t)kLazyLimit && spec_veto);
+            uint32_t tlen = spec_match ? spec_len : 1u;
+            unsigned long long match_lanes = __ballot(spec_match);
+            const bool is_open = level0 && canm && S.open;
+            unsigned long long open_mask = __ballot(is_open);
             // eight-token jumps for the chase: next start after 8 tokens and the starts passed on the way (three
             // doubling steps over ds_bpermute; a lone wave pays ~100 cycles per scalar hop otherwise).  The first
             // step's mask is known without a shuffle: the token after mine starts at lane n1, if that lane is live.
@@ -292,7 +304,8 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                 auto shfl64 = [](unsigned long long v, uint32_t src) {
                     return (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src) << 32 | (uint32_t)__shfl((int)(uint32_t)v, (int)src);
                 };
-                const uint32_t n1 = live ? min((uint32_t)lane + tlen, 64u) : 64u;
+                // (an open lane absorbs the chains that reach it: its length is not known yet)
+                const uint32_t n1 = live ? (is_open ? (uint32_t)lane : min((uint32_t)lane + tlen, 64u)) : 64u;
                 const bool v1 = n1 < 64u && P + (int)n1 < ilen;
                 const uint32_t n2g = (uint32_t)__shfl((int)n1, (int)(n1 & 63u));
                 const uint32_t n2 = v1 ? n2g : 64u;
@@ -333,6 +346,55 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             if (prof) { t2 = __builtin_readcyclecounter(); c_p1 += t1 - t0; c_mask += t2 - t1; n_round++; }
             unsigned long long acc = 0;              // accepted token starts of this round (committed or replayed)
             const bool near_cut = opos + 2 * 64 + 4 >= kSubSyms;
+
+            // Settle the open lane L (wave-uniform), all lanes helping: lane t compares bytes kOpenAt+4t .. +3 of the
+            // position with both chain nodes' sources (one coalesced round trip for up to 272 bytes each), the best-of
+            // rule and the lazy probe of speculate_l0 follow, and lane L's speculative registers take the result.
+            // Reads only the block's text and lane L's phase-1 registers, so it can run at any point of the round.
+            auto finish_open = [&](int L) {
+                unsigned long long tf0 = 0;
+                if (prof) tf0 = __builtin_readcyclecounter();
+                const uint32_t ol = rl(S.olen, L), offA = rl(S.off0, L), offB = rl(S.off1, L), ls = rl(S.lsrc1, L);
+                const bool lg0 = ((ol >> 16) & 1u) != 0, lg1 = ((ol >> 17) & 1u) != 0, h1s = ((ol >> 18) & 1u) != 0;
+                const uint32_t pL = (uint32_t)(P + L), t4 = 4u * (uint32_t)lane;
+                constexpr uint32_t K = kOpenAt;                    // bytes already known equal
+                const uint32_t a4 = ld32u(buf + (pL + K + t4));
+                const uint32_t b4 = ld32u(buf + ((lg0 ? offA : pL) + K + t4));
+                const uint32_t c4 = ld32u(buf + ((lg1 ? offB : pL) + K + t4));
+                const uint32_t e4 = ld32u(buf + (pL + K - 4u + t4));                                   // lazy probe operands,
+                const uint32_t d4 = ld32u(buf + (((ls >> 31) ? (ls & 0xFFFFFF) : pL) + K - 4u + t4));  // from byte K - 4 on
+                uint32_t l0 = ol & 0xFF, l1 = (ol >> 8) & 0xFF;
+                if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c_finw += __builtin_readcyclecounter() - tf0; }
+                if (lg0) {
+                    const unsigned long long m = __ballot(a4 != b4);
+                    uint32_t n = K + 256u;
+                    if (m) { const int f = (int)__builtin_ctzll(m); n = K + 4u * (uint32_t)f + ((uint32_t)__ffs((int)rl(a4 ^ b4, f)) - 1u) / 8u; }
+                    l0 = n < (uint32_t)kMatchMax ? n : (uint32_t)kMatchMax;
+                }
+                if (lg1) {
+                    const unsigned long long m = __ballot(a4 != c4);
+                    uint32_t n = K + 256u;
+                    if (m) { const int f = (int)__builtin_ctzll(m); n = K + 4u * (uint32_t)f + ((uint32_t)__ffs((int)rl(a4 ^ c4, f)) - 1u) / 8u; }
+                    l1 = n < (uint32_t)kMatchMax ? n : (uint32_t)kMatchMax;
+                }
+                uint32_t ml = kMatchMin - 1, mn = 0;
+                if (l0 > ml) { ml = l0; mn = rl(node0, L); }
+                if (h1s && ml != (uint32_t)kMatchMax && l1 > ml) { ml = l1; mn = (ol >> 19) & (kRing - 1); }
+                ml = ufl(ml);
+                bool veto = false;
+                if (ml < (uint32_t)kLazyLimit && (ls >> 31) != 0) {      // src/libzling_lz.cpp:291-316, depth 1
+                    const uint32_t i0 = ml + 2u - K, j0 = ml + 1u - K;    // byte ml-2 of the position / ml-3 of the source, counted from byte K-4
+                    const unsigned long long pw = (unsigned long long)rl(e4, (int)(i0 >> 2) + 1) << 32 | rl(e4, (int)(i0 >> 2));
+                    const unsigned long long sw = (unsigned long long)rl(d4, (int)(j0 >> 2) + 1) << 32 | rl(d4, (int)(j0 >> 2));
+                    veto = (uint32_t)(pw >> (8u * (i0 & 3u))) == (uint32_t)(sw >> (8u * (j0 & 3u)));
+                }
+                const bool nm = !(ml < (uint32_t)kLazyLimit && veto);
+                const uint32_t nsp = ml | mn << kSpNodeShift | kSpCanMatch | (veto ? kSpVeto1 : 0u) | (rl(sp, L) & (kSpRisk1 | kSpRisk2));
+                if (lane == L) { sp = nsp; S.len0 = l0; spec_len = ml; spec_match = nm; tlen = nm ? ml : 1u; }
+                match_lanes = (match_lanes & ~(1ull << L)) | (nm ? 1ull << L : 0ull);
+                open_mask &= ~(1ull << L);
+                if (prof) { n_fin++; c_fin += __builtin_readcyclecounter() - tf0; }
+            };
 
             // exact scalar replay of the token at q (wave-uniform): boundary event, match_exact / word MRU / literal
             // per-lane insert link and match node actually used (the in-register conflict fix may override the speculation)
@@ -398,7 +460,18 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                     unsigned long long tc = 0;
                     if (prof) tc = __builtin_readcyclecounter();
                     if ((seg >> s) & 1ull) seg &= ~((1ull << s) - 1ull);
-                    else { seg = 0; while (s < 64) { seg |= rl64(hop_mask, s); s = (int)rl(hop_next, s); } }
+                    else {
+                        seg = 0;
+                        while (s < 64) {
+                            seg |= rl64(hop_mask, s);
+                            int s2 = (int)rl(hop_next, s);
+                            if (s2 == s) {                   // an open lane: settle it (once), then its real length leads on
+                                if ((open_mask >> s) & 1ull) finish_open(s);
+                                s2 = s + (int)rl(tlen, s);
+                            }
+                            s = s2;
+                        }
+                    }
                     if (prof) c_chase += __builtin_readcyclecounter() - tc;
                     // ---- validate every lane against (acc | seg); only lanes of seg matter
                     unsigned long long tv = 0;
@@ -439,12 +512,15 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                         const bool cp = fixable && chk_p == chk;
                         uint32_t rp = cp ? lcp16(S.qa, qp) : 0u;
                         const bool lp = cp && rp == 16u;
-                        if (__any(lp)) { const uint32_t t = lcp_tail(buf + pos, buf + P + p, lp); rp = lp ? t : rp; }
                         // candidate of the second node
                         const bool c2 = fixable && has2 && chk_p2 == chk;
                         uint32_t r2 = c2 ? lcp16(S.qa, qp2) : 0u;
                         const bool l2 = c2 && r2 == 16u;
-                        if (__any(l2)) { const uint32_t t = lcp_tail(buf + pos, buf + P + p2, l2); r2 = l2 ? t : r2; }
+                        if (__any(lp || l2)) {
+                            uint32_t t0, t1;
+                            lcp_tail2(buf + pos, buf + P + p, buf + P + p2, lp, l2, t0, t1);
+                            rp = lp ? t0 : rp; r2 = l2 ? t1 : r2;
+                        }
                         const uint32_t slot_p = (head0 + (uint32_t)__popcll(ctxmask & all & ((1ull << p) - 1ull)) + 1u) & (kRing - 1);
                         const uint32_t slot_p2 = (head0 + (uint32_t)__popcll(ctxmask & all & ((1ull << p2) - 1ull)) + 1u) & (kRing - 1);
                         const bool second = has2 || node0 != 65535u;
@@ -574,7 +650,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     }
     if (prof && lane == 0) {
         unsigned long long* d = a.dbg + (size_t)blk * kDbgSlots;
-        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same; d[15] = c_val; d[16] = c_com;
+        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same; d[15] = c_val; d[16] = c_com; d[17] = n_fin; d[18] = c_fin; d[19] = c_finw;
     }
 }
 

@@ -406,11 +406,14 @@ __global__ __launch_bounds__(512) void k_rolz_parse_pipe(ParseArgs a) {
                         const bool cp = fixable && chk_p == chk;
                         uint32_t rp = cp ? lcp16(qa, qp) : 0u;
                         const bool lp = cp && rp == 16u;
-                        if (__any(lp)) { const uint32_t t = lcp_tail(buf + pos, buf + P + p, lp); rp = lp ? t : rp; }
                         const bool c2 = fixable && has2 && chk_p2 == chk;
                         uint32_t r2l = c2 ? lcp16(qa, qp2) : 0u;
                         const bool l2 = c2 && r2l == 16u;
-                        if (__any(l2)) { const uint32_t t = lcp_tail(buf + pos, buf + P + p2, l2); r2l = l2 ? t : r2l; }
+                        if (__any(lp || l2)) {
+                            uint32_t t0, t1;
+                            lcp_tail2(buf + pos, buf + P + p, buf + P + p2, lp, l2, t0, t1);
+                            rp = lp ? t0 : rp; r2l = l2 ? t1 : r2l;
+                        }
                         const uint32_t slot_p = (hbase + (uint32_t)__popcll(ctxmask & all & ((1ull << p) - 1ull)) + 1u) & (kRing - 1);
                         const uint32_t slot_p2 = (hbase + (uint32_t)__popcll(ctxmask & all & ((1ull << p2) - 1ull)) + 1u) & (kRing - 1);
                         const bool second = has2 || node0 != 65535u;

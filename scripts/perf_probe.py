@@ -1,4 +1,5 @@
-"""Stage timing probe: python scripts/perf_probe.py [MiB] [level] -- prints per-stage device ms."""
+"""Stage timing probe: python scripts/perf_probe.py [MiB] [level] [--check] [--real] -- prints per-stage device ms
+(--real: text files of this image, see real_text_soak.py, instead of the synthetic generator)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -11,7 +12,13 @@ mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 check = "--check" in sys.argv
 n = mib << 20
-x = textgen(n, 0)
+if "--real" in sys.argv:
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from real_text_soak import gather
+    x, _ = gather(n)
+    n = x.size
+else:
+    x = textgen(n, 0)
 nb = (n + zl.BLOCK - 1) // zl.BLOCK
 dx = torch.from_numpy(x).cuda()
 dx = torch.cat([dx, torch.zeros(512, dtype=torch.uint8, device="cuda")])
@@ -34,6 +41,13 @@ if os.environ.get("ZLNG_PROFILE") == "1":
     SL = 24
     buf = (C.c_ulonglong * (SL * nb))()
     zl.lib().zlng_debug_counters(C.c_void_p(s._h), buf, nb)
+    if "--all" in sys.argv:
+        for b in range(nb):
+            d = buf[SL * b: SL * b + 24]
+            r = max(d[3], 1)
+            print("blk %2d: %5.0f Mcyc  rounds %6d tokens %7d  per round p1 %5.0f mask %5.0f p2 %5.0f  settled tails %.2f/round  problem tokens %.2f/round (conflicts %.2f)  segments %.2f/round | p2 parts: chase+settle %4.0f validate %4.0f commit %4.0f serial %4.0f | per settled tail %4.0f cyc (%4.0f until the loads land)" % (
+                b, (d[0] + d[1] + d[2]) / 1e6, d[3], d[4], d[0] / r, d[1] / r, d[2] / r, d[17] / r, (d[6] + d[7]) / r, d[6] / r, d[5] / r,
+                d[9] / r, d[15] / r, d[16] / r, d[8] / r, d[18] / max(d[17], 1), d[19] / max(d[17], 1)))
     for b in range(min(nb, 4)):
         d = buf[SL * b: SL * b + 8]
         e = buf[SL * b + 8: SL * b + 24]
