@@ -194,16 +194,10 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                 const uint32_t hp = hash_of(qap.a);
                 Spec S;
                 const uint32_t pctx = wpp >> 24, pl1 = qap.a & 0xFF, pl2 = (qap.a >> 8) & 0xFF;
-                if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) speculate_l0<true>(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
-                else speculate(S, dict, buf, heads[pctx], heads[pl1], heads[pl2], kRiskDist, pos, pcfg, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) {
+                    speculate_l0<true>(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                } else speculate(S, dict, buf, heads[pctx], heads[pl1], heads[pl2], kRiskDist, pos, pcfg, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
-                // an open lane's tail is settled by one dependent round trip in phase 2 if it is a token start: pull
-                // the next line of both sources towards L2 now (the 16 compared bytes already brought the first)
-                if (S.open) {
-                    const uint32_t t0 = ld32u(buf + ((S.olen >> 16) & 1u ? S.off0 + 128u : (uint32_t)pos));
-                    const uint32_t t1 = ld32u(buf + ((S.olen >> 17) & 1u ? S.off1 + 128u : (uint32_t)pos));
-                    asm volatile("" :: "v"(t0), "v"(t1));
-                }
             }
             done_to = start + 64;
         }

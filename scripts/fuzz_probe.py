@@ -8,7 +8,7 @@ from test_gpu_fuzz import make_input
 o = Oracle()
 text = textgen(3_000_000, 200)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
-for kind in range(7):
+for kind in range(8):
     for lv in (0, 4):
         rng = np.random.Generator(np.random.PCG64(kind))
         x = np.ascontiguousarray(make_input(rng, kind, n, text))

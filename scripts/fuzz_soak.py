@@ -17,7 +17,7 @@ with zl.Stream(0, 0, True, 2) as s0, zl.Stream(0, 2, True, 2) as s2, zl.Stream(0
     st = {lv: s.get_state() for lv, s in streams.items()}
     for seed in range(1000, 1000 + seeds):
         rng = np.random.Generator(np.random.PCG64(seed))
-        for kind in range(7):
+        for kind in range(8):
             n = int(rng.integers(1, cap))
             x = np.ascontiguousarray(make_input(rng, kind, n, text))
             for lv, s in streams.items():

@@ -46,6 +46,19 @@ def make_input(rng, kind, n, text):
             m = int(rng.integers(1000, 400_000))
             out.append(rng.integers(0, 256, m, dtype=np.uint8) if rng.random() < 0.5 else text[:m]); tot += m
         return np.concatenate(out)[:n]
+    if kind == 7:                                   # copies of earlier stretches, 17..600 bytes long, some edited: long and
+        x = text[:n].copy()                         # mid-length matches, lazy probes at long lengths (source-code-like)
+        at = 64
+        while at + 700 < n:
+            m = int(rng.integers(17, 600))
+            src = int(rng.integers(0, at - 16)) if rng.random() < 0.7 else max(0, at - int(rng.integers(1, 40)))
+            m = min(m, at - src) if rng.random() < 0.5 else m
+            for k in range(m):                      # (byte by byte: a source may overlap its copy)
+                x[at + k] = x[src + k]
+            if rng.random() < 0.3:
+                x[at + int(rng.integers(0, m))] ^= 1
+            at += m + int(rng.integers(0, 30))
+        return x
     return rng.integers(0, 256, n, dtype=np.uint8)  # plain noise
 
 
@@ -55,8 +68,8 @@ def test_differential_vs_oracle_and_roundtrip(oracle, seed):
     from oracle_py import textgen
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     text = textgen(3_000_000, 200 + seed)
-    for it in range(7):
-        kind = (seed + it) % 7
+    for it in range(8):
+        kind = (seed + it) % 8
         n = int(rng.integers(1, 900_000)) if it else int(rng.integers(1, 600))
         x = np.ascontiguousarray(make_input(rng, kind, n, text))
         lv = int(rng.integers(0, 5))
