@@ -32,15 +32,20 @@ __device__ __forceinline__ int common_len(const uint8_t* a, const uint8_t* b) {
 // One context's dictionary plane.  Fields are addressed as (wave-uniform base) + (32-bit byte offset): the whole
 // per-block dictionary is 10 MiB, so the offset fits a VGPR and every access is a global_load/store with an SGPR
 // base ("saddr") -- no 64-bit per-lane pointer arithmetic.
-template <class T> struct BktField {
+template <class T, uint32_t kStride = (uint32_t)sizeof(T)> struct BktField {
     uint8_t* d; uint32_t o;
-    __device__ __forceinline__ T& operator[](uint32_t i) const { return *reinterpret_cast<T*>(d + (o + (uint32_t)sizeof(T) * i)); }
+    __device__ __forceinline__ T& operator[](uint32_t i) const { return *reinterpret_cast<T*>(d + (o + kStride * i)); }
 };
 struct Bucket {
-    BktField<uint32_t> offset; BktField<uint16_t> suffix; BktField<uint16_t> hash;
+    BktField<uint32_t, 8> offset;              // a slot's own word
+    BktField<uint32_t, 8> pred;                // the linked slot's word as of the time the link was made
+    BktField<unsigned long long, 8> slot;      // both
+    BktField<uint16_t> suffix; BktField<uint16_t> hash;
     __device__ __forceinline__ Bucket(uint8_t* dict, uint32_t ctx) {
         const uint32_t b = ctx * kBktBytes;
         offset = {dict, b + kBktOffsetOff};
+        pred   = {dict, b + kBktOffsetOff + 4u};
+        slot   = {dict, b + kBktOffsetOff};
         suffix = {dict, b + kBktSuffixOff};
         hash   = {dict, b + kBktHashOff};
     }
@@ -64,6 +69,8 @@ __device__ __forceinline__ bool lazy_probe(uint8_t* dict, const uint8_t* buf, in
 // MatchAndUpdate, src/libzling_lz.cpp:211-289 (insert first, then walk <= depth chain nodes).
 // `head` is the ring slot this insert takes (the caller owns the per-context head counters).
 // Safe to run wave-uniformly: every lane computes the same thing, lane 0 alone stores.
+// kCopy: also keep the slot's copy of its link's word (the wave parser's inserts; see zlng_common.h).
+template <bool kCopy = false>
 __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, int pos, const LevelCfg cfg,
                                             uint32_t head, bool writer, int& match_idx, int& match_len) {
     uint32_t h = hash4(buf + pos);
@@ -72,9 +79,13 @@ __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, i
     uint32_t ctx = buf[pos - 1];
     Bucket B(dict, ctx);
     uint32_t node = B.hash[hc];
+    const uint32_t own = (uint32_t)pos | chk << 24;
+    uint32_t ov_first = 0;
+    if (kCopy && node != 65535 && node != head) ov_first = B.offset[node];
     if (writer) {
         B.suffix[head] = (uint16_t)node;
-        B.offset[head] = (uint32_t)pos | chk << 24;
+        if (kCopy) B.slot[head] = (unsigned long long)own | (unsigned long long)(node == head ? own : ov_first) << 32;
+        else B.offset[head] = own;
         B.hash[hc] = (uint16_t)head;
     }
     if (node == 65535 || node == head) return false;
@@ -84,7 +95,7 @@ __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, i
     for (int i = 0; i < cfg.depth; i++) {
         // the slot just written is read back as written (it is `head`, checked above for i == 0;
         // later hits on it end the chain through the position test exactly as in the reference)
-        uint32_t ov = node == head ? ((uint32_t)pos | chk << 24) : B.offset[node];
+        uint32_t ov = node == head ? own : (kCopy && i == 0) ? ov_first : B.offset[node];
         uint32_t off = ov & 0xFFFFFF;
         if ((ov >> 24) == chk && buf[pos + maxlen] == buf[off + maxlen]) {
             int len = common_len(buf + pos, buf + off);
@@ -174,12 +185,13 @@ struct Spec {
     // alone, the lazy probe's source offset (bit 31: probe chain non-empty), the 16 input bytes at the position
     uint32_t len0, lsrc1;
     Quad qa;
-    // level 0 with deferred tails (speculate_l0<true>): a lane whose compare against a chain node reached 16 bytes is
+    // level 0 in the wave parser (speculate_l0w): a lane whose compare against a chain node reached 16 bytes is
     // "open" -- its lengths are lower bounds and its lazy probe has not been evaluated -- until the parser finishes it
     // (only token starts are ever finished).  off0 / off1: sources of the two nodes; olen: len0 | len1 << 8 |
     // long0 << 16 | long1 << 17 | node 1 exists << 18 | node 1's ring slot << 19.
     uint32_t off0, off1, olen;
     bool open;
+    uint32_t ov0;                        // node 0's slot word (the inserting lane stores it as its link's copy)
 };
 
 __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
@@ -250,6 +262,7 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     const uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
     uint32_t ov = B.offset[node0 & (kRing - 1)];
     uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    S.ov0 = ov;                                      // the inserting lane stores it as its link's copy
     const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
     const uint32_t lsf1 = B1.suffix[ln1 & (kRing - 1)], lsf2 = B2.suffix[ln2 & (kRing - 1)];
 
@@ -320,10 +333,8 @@ __device__ __forceinline__ void lcp_tail2(const uint8_t* a, const uint8_t* b, co
     r1 = r1 < (uint32_t)kMatchMax ? r1 : (uint32_t)kMatchMax;
 }
 
-constexpr uint32_t kOpenAt = 16;                     // deferred tails: bytes compared in phase 1 before a lane is left open.  48 (one 32-byte step
-                                                     // for every long lane in phase 1) was measured too: real text -2 %, the benchmark text +2 %
-
-template <bool kDefer = false>
+// Level 0 (depth 2, one lazy probe at +1) as straight-line predicated code: five dependent round trips after the
+// window's text.  Used by the pipelined parser (rolz_pipe.hip); the wave parser runs speculate_l0w below.
 __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t risk_dist, int pos,
                                              const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t w4 = qa.a;
@@ -355,27 +366,7 @@ __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8
     const Quad q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
     uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
     const bool long1 = cmp1 && len1 == 16u;
-    bool open = false;
-    if (kDefer) {
-        bool o0 = long0, o1 = long1;
-        if (kOpenAt > 16u && __any(long0 || long1)) {            // bytes 16 .. 47 of every long lane, here and now
-            const uint8_t* pa = buf + pos;
-            const uint8_t* pb = long0 ? buf + off0 : pa;
-            const uint8_t* pc = long1 ? buf + off1 : pa;
-            const Quad a0 = ld128u(pa + 16), a1 = ld128u(pa + 32);
-            const Quad b0 = ld128u(pb + 16), b1 = ld128u(pb + 32);
-            const Quad c0 = ld128u(pc + 16), c1 = ld128u(pc + 32);
-            uint32_t d0 = first_diff16(a0, b0);
-            if (d0 == 16u) d0 += first_diff16(a1, b1);
-            uint32_t d1 = first_diff16(a0, c0);
-            if (d1 == 16u) d1 += first_diff16(a1, c1);
-            if (long0) { len0 = 16u + d0; o0 = d0 == 32u; }
-            if (long1) { len1 = 16u + d1; o1 = d1 == 32u; }
-        }
-        open = o0 || o1;
-        S.off0 = off0; S.off1 = off1; S.open = open;
-        S.olen = len0 | len1 << 8 | (o0 ? 1u << 16 : 0u) | (o1 ? 1u << 17 : 0u) | (has1s ? 1u << 18 : 0u) | (nx & (kRing - 1)) << 19;
-    } else if (__any(long0 || long1)) {
+    if (__any(long0 || long1)) {
         uint32_t t0, t1;
         lcp_tail2(buf + pos, buf + off0, buf + off1, long0, long1, t0, t1);
         len0 = long0 ? t0 : len0;
@@ -390,9 +381,7 @@ __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8
     dmin = has1 ? min(dmin, ring_dist(nx, head0)) : dmin;          // its offset was read for the chain-end test
     uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
     // round trip 5: the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1)
-    // (an open lane's probe waits for its final length; dmin above may count node 1 although node 0 turns out to
-    //  have the maximum length: a conflict flagged for nothing only costs an exact replay)
-    const bool lz1 = !open && maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
+    const bool lz1 = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
     const uint32_t m = lz1 ? maxlen - 3u : 0u;
     const uint32_t probe = ld32u(buf + ((uint32_t)pos + 1u + m));
     const uint32_t srcw = ld32u(buf + ((lz1 && hasl) ? (lov1 & 0xFFFFFF) + m : (uint32_t)pos));
@@ -404,6 +393,78 @@ __device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8
     S.ld1 = ld1; S.ld2 = kRing - 1;
     S.lz1 = lz1; S.lz2 = false;
     S.len0 = len0; S.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u); S.qa = qa;
+}
+
+constexpr uint32_t kOpenAt = 16;                     // bytes compared in phase 1 before a lane is left open (see Spec)
+
+// The wave parser's level-0 speculation: three dependent round trips after the window's text.
+//  * A ring slot carries a copy of its link's word (zlng_common.h), so node 1 needs no load of its own.  The copy was
+//    taken when node 0 was written; the reference reads the linked slot now.  They differ only if that slot has been
+//    rewritten since -- it lies in (node0, head] of the ring -- and then it holds a position later than node 0's, so
+//    the reference's chain-end test (src/libzling_lz.cpp:265, `offset[node] <= offset[next]`) stops the walk: the
+//    same outcome as having no node 1.  (The slot still counts as read: in-round conflicts are judged on it.)
+//  * Lanes whose compare reaches 16 bytes are left open (Spec); every other match is at most 15 long, so the lazy
+//    probe's two words lie within bytes 1..16 of the position (qa and `t16`, the 4 bytes after it) and bytes
+//    0..15 of the probe node's source, fetched together with the compare blocks.
+__device__ __forceinline__ void speculate_l0w(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t risk_dist, int pos,
+                                              const Quad qa, uint32_t t16, uint32_t ctx, uint32_t hc, uint32_t chk) {
+    const uint32_t w4 = qa.a;
+    const uint32_t lctx1 = w4 & 0xFF;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    Bucket B(dict, ctx), B1(dict, lctx1);
+    // round trip 1: both hash heads
+    const uint32_t node0 = B.hash[hc];
+    const uint32_t ln1 = B1.hash[hh1];
+    const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
+    // round trip 2: node 0's slot (own word + its link's), its link, the probe node's word
+    const unsigned long long sl0 = B.slot[node0 & (kRing - 1)];
+    const uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)];
+    const uint32_t ov0 = (uint32_t)sl0, nov = (uint32_t)(sl0 >> 32);
+    const uint32_t off0 = ov0 & 0xFFFFFF, off1 = nov & 0xFFFFFF;
+    const bool has1s = has0 && nx != 65535u;
+    const uint32_t dnx = (nx - node0) & (kRing - 1), age0 = (head0 - node0) & (kRing - 1);
+    const bool rewritten = dnx != 0u && dnx <= age0;
+    const bool go1 = has1s && !rewritten && !(off0 <= off1);
+    // round trip 3: compare blocks of both nodes, first 16 source bytes of the lazy probe
+    const bool cmp0 = has0 && (ov0 >> 24) == chk;
+    const bool cmp1 = go1 && (nov >> 24) == chk;
+    const Quad q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
+    const Quad q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
+    const Quad ql = ld128u(buf + (hasl ? (lov1 & 0xFFFFFF) : (uint32_t)pos));
+    const uint32_t len0 = cmp0 ? lcp16(qa, q0) : 0u;
+    const uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
+    const bool long0 = cmp0 && len0 == 16u, long1 = cmp1 && len1 == 16u;
+    const bool open = long0 || long1;
+    S.off0 = off0; S.off1 = off1; S.open = open;
+    S.olen = len0 | len1 << 8 | (long0 ? 1u << 16 : 0u) | (long1 ? 1u << 17 : 0u) | (has1s ? 1u << 18 : 0u) | (nx & (kRing - 1)) << 19;
+    uint32_t maxlen = kMatchMin - 1, maxnode = 0;
+    if (len0 > maxlen) { maxlen = len0; maxnode = node0; }
+    const bool has1 = has1s && maxlen != (uint32_t)kMatchMax;
+    if (has1 && len1 > maxlen) { maxlen = len1; maxnode = nx; }
+    uint32_t dmin = kRing - 1;
+    dmin = has0 ? min(dmin, ring_dist(node0, head0)) : dmin;
+    dmin = has1 ? min(dmin, ring_dist(nx, head0)) : dmin;          // the reference reads its offset for the chain-end test
+    uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
+    // the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1): position bytes m+1 .. m+4 against source bytes
+    // m .. m+3, m = maxlen - 3 <= 12.  (An open lane's probe waits for its final length; its dmin may count node 1
+    // although node 0 turns out to have the maximum length: a conflict flagged for nothing only costs an exact replay.)
+    const bool lz1 = !open && maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
+    const uint32_t m = lz1 ? maxlen - 3u : 0u;
+    const uint32_t x0 = __builtin_amdgcn_alignbyte(qa.b, qa.a, 1u) ^ ql.a, x1 = __builtin_amdgcn_alignbyte(qa.c, qa.b, 1u) ^ ql.b;
+    const uint32_t x2 = __builtin_amdgcn_alignbyte(qa.d, qa.c, 1u) ^ ql.c, x3 = __builtin_amdgcn_alignbyte(t16, qa.d, 1u) ^ ql.d;
+    const uint32_t dw = m >> 2;
+    const uint32_t xl = dw == 0u ? x0 : dw == 1u ? x1 : dw == 2u ? x2 : x3;
+    const uint32_t xh = dw == 0u ? x1 : dw == 1u ? x2 : x3;               // (dw == 3 only with m == 12: no byte of xh is used)
+    if (lz1 && hasl && __builtin_amdgcn_alignbyte(xh, xl, m & 3u) == 0u) sp |= kSpVeto1;
+    const uint32_t ld1 = hasl ? ring_dist(ln1, lhead1) : (uint32_t)kRing - 1u;
+    if (ld1 < risk_dist) sp |= kSpRisk1;                                  // (kept even when no probe was needed: the conflict fix may need one)
+    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
+    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = 0; S.lctx1 = lctx1; S.lctx2 = 0;
+    S.ld1 = ld1; S.ld2 = kRing - 1;
+    S.lz1 = lz1; S.lz2 = false;
+    S.len0 = len0; S.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u); S.qa = qa;
+    S.ov0 = ov0;
 }
 
 // Ordering point for LDS traffic inside ONE wavefront (program order is execution order for a wave's LDS

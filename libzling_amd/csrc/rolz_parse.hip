@@ -16,9 +16,9 @@ namespace zlng {
 
 // ------------------------------------------------------------------------------ K0
 // Reset(): offset = 0, suffix = 0xFFFF, hash = 0xFFFF for every bucket (src/libzling_lz.cpp:197-209).
-// Pure streaming fill: 10.5 MB per block, 16 B per lane per store.
+// Pure streaming fill: 14.7 MB per block, 16 B per lane per store.
 __global__ __launch_bounds__(256) void k_dict_reset(uint8_t* dict, uint32_t nblocks) {
-    const size_t vec_per_bkt = kBktBytes / 16;                       // 2560 uint4 per bucket
+    const size_t vec_per_bkt = kBktBytes / 16;                       // 3584 uint4 per bucket
     const size_t total = (size_t)nblocks * 256 * vec_per_bkt;
     uint4* d = reinterpret_cast<uint4*>(dict);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                 Spec S;
                 const uint32_t pctx = wpp >> 24, pl1 = qap.a & 0xFF, pl2 = (qap.a >> 8) & 0xFF;
                 if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) {
-                    speculate_l0<true>(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                    speculate_l0w(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, 0u, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 } else speculate(S, dict, buf, heads[pctx], heads[pl1], heads[pl2], kRiskDist, pos, pcfg, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
             }
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             const uint32_t upos = (uint32_t)pos;
             const uint32_t wraw = ld32u(buf + (upos >= 4u ? upos - 4u : 0u));
             const Quad qtext = ld128u(buf + upos);
+            const uint32_t t16 = ld32u(buf + (upos + 16u));
             const uint32_t wp = upos >= 4u ? wraw : wraw << ((8u * (4u - upos)) & 31u);
             const uint32_t w4 = live ? qtext.a : 0u;
             const uint32_t ctx = wp >> 24;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             S.lkix1 = S.lkix2 = S.lctx1 = S.lctx2 = 0; S.lz1 = S.lz2 = false;
             S.ld1 = S.ld2 = kRing - 1;
             S.len0 = 0; S.lsrc1 = 0; S.qa = Quad{0, 0, 0, 0};
-            S.off0 = S.off1 = S.olen = 0; S.open = false;
+            S.off0 = S.off1 = S.olen = 0; S.open = false; S.ov0 = 0;
             const uint32_t kix_w = canm ? kix : (uint32_t)kKeyTab, ctx_w = canm ? ctx : 256u;
             atomicOr(&keytab[kix_w], lane_bit);
             atomicOr(&ctxtab[ctx_w], lane_bit);
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             // without room for a match (the last 275 bytes of the block) reads at most 354 bytes past the block -- the
             // next block's text or the boundary's 512 readable bytes -- and everything derived from its result is
             // gated by canm below.
-            if (level0) speculate_l0<true>(S, dict, buf, heads[ctx], heads[w4 & 0xFF], kRiskDist, pos, qtext, ctx, hc, chk);
+            if (level0) speculate_l0w(S, dict, buf, heads[ctx], heads[w4 & 0xFF], kRiskDist, pos, qtext, t16, ctx, hc, chk);
             else if (canm) speculate(S, dict, buf, heads[ctx], heads[w4 & 0xFF], heads[(w4 >> 8) & 0xFF], kRiskDist, pos, cfg, qtext, ctx, hc, chk);
             uint32_t sp = (level0 && !canm) ? (uint32_t)(kMatchMin - 1) : S.sp;
             const uint32_t node0 = S.node0, head0 = S.head0, dmin = S.dmin;
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             // exact scalar replay of the token at q (wave-uniform): boundary event, match_exact / word MRU / literal
             // per-lane insert link and match node actually used (the in-register conflict fix may override the speculation)
             uint32_t node0w = node0, mnode = (sp >> kSpNodeShift) & (kRing - 1);
+            uint32_t pword = S.ov0;                  // word of the slot node0w (stored beside my own word: the link's copy)
             auto serial_token = [&](bool use_spec) {
                 const int sl = q - P;
                 const uint32_t xk = rl(ek, sl), xw = rl(ew, sl);
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                         if (lane == sl) {
                             Bucket B(dict, ctx);
                             B.suffix[head] = (uint16_t)node0w;
-                            B.offset[head] = (uint32_t)pos | chk << 24;
+                            B.slot[head] = (unsigned long long)((uint32_t)pos | chk << 24) | (unsigned long long)pword << 32;
                             B.hash[hc] = (uint16_t)head;
                         }
                         is_match = ((match_lanes >> sl) & 1ull) != 0;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                         midx = (int)((head - rl(mnode, sl)) & (kRing - 1));
                     } else {
                         int mi = 0, ml = 0;
-                        const bool hit = match_exact(dict, buf, q, cfg, head, lane == 0, mi, ml);
+                        const bool hit = match_exact<true>(dict, buf, q, cfg, head, lane == 0, mi, ml);
                         is_match = __builtin_amdgcn_readfirstlane((int)hit) != 0;
                         mlen = __builtin_amdgcn_readfirstlane(ml);
                         midx = __builtin_amdgcn_readfirstlane(mi);
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                     // the chase stays valid; everything else falls back to the restart / exact-replay path.
                     bool fixed_ok = false;
                     int pfix = 0;
-                    node0w = node0; mnode = (sp >> kSpNodeShift) & (kRing - 1);
+                    node0w = node0; mnode = (sp >> kSpNodeShift) & (kRing - 1); pword = S.ov0;
                     const bool inseg = (seg & lane_bit) != 0;
                     if (level0 && __any(inseg && kq != 0 && !ring)) {
                         const bool cand = inseg && kq != 0 && !ring;
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                         }
                         const bool nmatch = ml >= (uint32_t)kMatchMin && !(lzn && veto);
                         fixed_ok = fixable && lclean && nmatch == spec_match && (!nmatch || ml == spec_len);
-                        if (fixed_ok) { node0w = slot_p; mnode = mn; pfix = p; }
+                        if (fixed_ok) { node0w = slot_p; mnode = mn; pfix = p; pword = (uint32_t)(P + p) | chk_p << 24; }
                     }
                     const bool dirty = canm && (kq != 0 || ring) && !fixed_ok;
                     const bool ldirty = !fixed_ok && spec_len >= (uint32_t)kMatchMin && spec_len < (uint32_t)kLazyLimit && (lkey & all & beloweq) != 0;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                             if (canm) {
                                 Bucket B(dict, ctx);
                                 B.suffix[head] = (uint16_t)node0w;
-                                B.offset[head] = (uint32_t)pos | chk << 24;
+                                B.slot[head] = (unsigned long long)((uint32_t)pos | chk << 24) | (unsigned long long)pword << 32;
                                 // several starts of one hash slot can commit together now; the slot's head must end up
                                 // being the last of them, so a lane that is the predecessor of a later one does not write it
                                 if (head_writer) B.hash[hc] = (uint16_t)head;

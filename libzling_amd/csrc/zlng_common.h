@@ -28,14 +28,16 @@ constexpr int kHeaderBytes = 13;        // flag + 3 x u32be
 // One 16 MiB block can hold at most 16Mi one-byte tokens -> <= 65 sub-blocks; 80 leaves slack.
 constexpr int kMaxSub = 80;
 
-// ---- HBM layout of one context's dictionary: 256 buckets x 40,960 B ------------------
-// (the reference's ZlingEncodeBucket, src/libzling_lz.h:98-103, re-laid as three planes so the
-//  hot `offset` plane of a bucket is one 16 KiB run; `head` lives in LDS during a parse)
-constexpr uint32_t kBktOffsetOff = 0;                       // u32[4096]  pos | hash_check << 24
-constexpr uint32_t kBktSuffixOff = 4 * kRing;               // u16[4096]
-constexpr uint32_t kBktHashOff   = 4 * kRing + 2 * kRing;   // u16[8192]
-constexpr uint32_t kBktBytes     = 4 * kRing + 2 * kRing + 2 * kHashSlots;   // 40,960
-constexpr size_t   kDictBytes    = (size_t)256 * kBktBytes;                  // 10,485,760 per block
+// ---- HBM layout of one context's dictionary: 256 buckets x 57,344 B ------------------
+// (the reference's ZlingEncodeBucket, src/libzling_lz.h:98-103, re-laid as three planes; `head` lives in LDS
+//  during a parse.  A ring slot is 8 bytes: its own word and a copy of the word of the slot it links to, taken
+//  when the link was made -- the wave parser reads a chain's second node without a dependent load; rolz_dev.h
+//  `speculate_l0w` says when the copy is what the reference would read and what follows when it is not)
+constexpr uint32_t kBktOffsetOff = 0;                       // {u32 pos | hash_check << 24, u32 same word of the linked slot}[4096]
+constexpr uint32_t kBktSuffixOff = 8 * kRing;               // u16[4096]
+constexpr uint32_t kBktHashOff   = 8 * kRing + 2 * kRing;   // u16[8192]
+constexpr uint32_t kBktBytes     = 8 * kRing + 2 * kRing + 2 * kHashSlots;   // 57,344
+constexpr size_t   kDictBytes    = (size_t)256 * kBktBytes;                  // 14,680,064 per block
 
 // ---- token word (same as oracle/zlng_oracle.h) ---------------------------------------
 //  bits 0..15  alphabet-1 symbol (raw byte before the rank stage, rank after it)
