@@ -36,24 +36,25 @@ template <class T, uint32_t kStride = (uint32_t)sizeof(T)> struct BktField {
     uint8_t* d; uint32_t o;
     __device__ __forceinline__ T& operator[](uint32_t i) const { return *reinterpret_cast<T*>(d + (o + kStride * i)); }
 };
-struct Bucket {
-    BktField<uint32_t, 8> offset;              // a slot's own word
-    BktField<uint32_t, 8> pred;                // the linked slot's word as of the time the link was made
-    BktField<unsigned long long, 8> slot;      // both
+template <bool kWide> struct BucketT {
+    static constexpr uint32_t kSlot = kWide ? 8u : 4u;
+    BktField<uint32_t, kSlot> offset;          // a slot's own word
+    BktField<unsigned long long, 8> slot;      // wide form only: own word + the linked slot's word as of the time the link was made
     BktField<uint16_t> suffix; BktField<uint16_t> hash;
-    __device__ __forceinline__ Bucket(uint8_t* dict, uint32_t ctx) {
+    __device__ __forceinline__ BucketT(uint8_t* dict, uint32_t ctx) {
         const uint32_t b = ctx * kBktBytes;
-        offset = {dict, b + kBktOffsetOff};
-        pred   = {dict, b + kBktOffsetOff + 4u};
-        slot   = {dict, b + kBktOffsetOff};
-        suffix = {dict, b + kBktSuffixOff};
-        hash   = {dict, b + kBktHashOff};
+        offset = {dict, b};
+        slot   = {dict, b};
+        suffix = {dict, b + kSlot * kRing};
+        hash   = {dict, b + kSlot * kRing + 2u * kRing};
     }
 };
+using Bucket = BucketT<false>;
 
 // MatchLazy, src/libzling_lz.cpp:291-316
+template <bool kWide = false>
 __device__ __forceinline__ bool lazy_probe(uint8_t* dict, const uint8_t* buf, int pos, int maxlen, int depth) {
-    Bucket B(dict, buf[pos - 1]);
+    BucketT<kWide> B(dict, buf[pos - 1]);
     uint32_t node = B.hash[hash4(buf + pos) % kHashSlots];
     if (node == 65535) return false;
     int m = maxlen - 3;
@@ -69,7 +70,7 @@ __device__ __forceinline__ bool lazy_probe(uint8_t* dict, const uint8_t* buf, in
 // MatchAndUpdate, src/libzling_lz.cpp:211-289 (insert first, then walk <= depth chain nodes).
 // `head` is the ring slot this insert takes (the caller owns the per-context head counters).
 // Safe to run wave-uniformly: every lane computes the same thing, lane 0 alone stores.
-// kCopy: also keep the slot's copy of its link's word (the wave parser's inserts; see zlng_common.h).
+// kCopy: the wide slot plane, the insert also stores the copy of its link's word (zlng_common.h).
 template <bool kCopy = false>
 __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, int pos, const LevelCfg cfg,
                                             uint32_t head, bool writer, int& match_idx, int& match_len) {
@@ -77,7 +78,7 @@ __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, i
     uint32_t chk = (h / kHashSlots) & 255u;
     uint32_t hc = h % kHashSlots;
     uint32_t ctx = buf[pos - 1];
-    Bucket B(dict, ctx);
+    BucketT<kCopy> B(dict, ctx);
     uint32_t node = B.hash[hc];
     const uint32_t own = (uint32_t)pos | chk << 24;
     uint32_t ov_first = 0;
@@ -109,8 +110,8 @@ __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, i
     }
     if (maxlen < kMatchMin) return false;
     if (maxlen < kLazyLimit) {
-        if (cfg.lazy1 > 0 && lazy_probe(dict, buf, pos + 1, maxlen, cfg.lazy1)) return false;
-        if (cfg.lazy2 > 0 && lazy_probe(dict, buf, pos + 2, maxlen, cfg.lazy2)) return false;
+        if (cfg.lazy1 > 0 && lazy_probe<kCopy>(dict, buf, pos + 1, maxlen, cfg.lazy1)) return false;
+        if (cfg.lazy2 > 0 && lazy_probe<kCopy>(dict, buf, pos + 2, maxlen, cfg.lazy2)) return false;
     }
     match_len = maxlen;
     match_idx = (int)((head - maxnode) & (kRing - 1));
@@ -406,32 +407,48 @@ constexpr uint32_t kOpenAt = 16;                     // bytes compared in phase 
 //  * Lanes whose compare reaches 16 bytes are left open (Spec); every other match is at most 15 long, so the lazy
 //    probe's two words lie within bytes 1..16 of the position (qa and `t16`, the 4 bytes after it) and bytes
 //    0..15 of the probe node's source, fetched together with the compare blocks.
+template <bool kWide>
 __device__ __forceinline__ void speculate_l0w(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t risk_dist, int pos,
                                               const Quad qa, uint32_t t16, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t w4 = qa.a;
     const uint32_t lctx1 = w4 & 0xFF;
     const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
-    Bucket B(dict, ctx), B1(dict, lctx1);
+    BucketT<kWide> B(dict, ctx), B1(dict, lctx1);
     // round trip 1: both hash heads
     const uint32_t node0 = B.hash[hc];
     const uint32_t ln1 = B1.hash[hh1];
     const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
-    // round trip 2: node 0's slot (own word + its link's), its link, the probe node's word
-    const unsigned long long sl0 = B.slot[node0 & (kRing - 1)];
+    // round trip 2: node 0's slot (wide: own word + its link's), its link, the probe node's word
+    uint32_t ov0, nov = 0;
+    if (kWide) { const unsigned long long sl0 = B.slot[node0 & (kRing - 1)]; ov0 = (uint32_t)sl0; nov = (uint32_t)(sl0 >> 32); }
+    else ov0 = B.offset[node0 & (kRing - 1)];
     const uint32_t nx = B.suffix[node0 & (kRing - 1)];
     const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)];
-    const uint32_t ov0 = (uint32_t)sl0, nov = (uint32_t)(sl0 >> 32);
-    const uint32_t off0 = ov0 & 0xFFFFFF, off1 = nov & 0xFFFFFF;
+    const uint32_t off0 = ov0 & 0xFFFFFF;
     const bool has1s = has0 && nx != 65535u;
-    const uint32_t dnx = (nx - node0) & (kRing - 1), age0 = (head0 - node0) & (kRing - 1);
-    const bool rewritten = dnx != 0u && dnx <= age0;
-    const bool go1 = has1s && !rewritten && !(off0 <= off1);
-    // round trip 3: compare blocks of both nodes, first 16 source bytes of the lazy probe
     const bool cmp0 = has0 && (ov0 >> 24) == chk;
-    const bool cmp1 = go1 && (nov >> 24) == chk;
-    const Quad q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
-    const Quad q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
-    const Quad ql = ld128u(buf + (hasl ? (lov1 & 0xFFFFFF) : (uint32_t)pos));
+    Quad q0, q1, ql;
+    uint32_t off1;
+    bool cmp1;
+    if (kWide) {
+        const uint32_t dnx = (nx - node0) & (kRing - 1), age0 = (head0 - node0) & (kRing - 1);
+        const bool rewritten = dnx != 0u && dnx <= age0;
+        off1 = nov & 0xFFFFFF;
+        cmp1 = has1s && !rewritten && !(off0 <= off1) && (nov >> 24) == chk;
+        // round trip 3: compare blocks of both nodes, first 16 source bytes of the lazy probe
+        q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
+        q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
+        ql = ld128u(buf + (hasl ? (lov1 & 0xFFFFFF) : (uint32_t)pos));
+    } else {
+        // compact plane: node 1's word is a dependent load (round trip 3, beside node 0's compare block and the
+        // probe's source bytes), its compare block a fourth round trip
+        q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
+        nov = B.offset[nx & (kRing - 1)];
+        ql = ld128u(buf + (hasl ? (lov1 & 0xFFFFFF) : (uint32_t)pos));
+        off1 = nov & 0xFFFFFF;
+        cmp1 = has1s && !(off0 <= off1) && (nov >> 24) == chk;
+        q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
+    }
     const uint32_t len0 = cmp0 ? lcp16(qa, q0) : 0u;
     const uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
     const bool long0 = cmp0 && len0 == 16u, long1 = cmp1 && len1 == 16u;

@@ -16,14 +16,15 @@ namespace zlng {
 
 // ------------------------------------------------------------------------------ K0
 // Reset(): offset = 0, suffix = 0xFFFF, hash = 0xFFFF for every bucket (src/libzling_lz.cpp:197-209).
-// Pure streaming fill: 14.7 MB per block, 16 B per lane per store.
-__global__ __launch_bounds__(256) void k_dict_reset(uint8_t* dict, uint32_t nblocks) {
+// Pure streaming fill: 14.7 MB per block, 16 B per lane per store.  `slot_bytes`: size of the slot plane in the
+// form the following parse uses (zlng_common.h); what lies behind the planes of the compact form is filled too.
+__global__ __launch_bounds__(256) void k_dict_reset(uint8_t* dict, uint32_t nblocks, uint32_t slot_bytes) {
     const size_t vec_per_bkt = kBktBytes / 16;                       // 3584 uint4 per bucket
     const size_t total = (size_t)nblocks * 256 * vec_per_bkt;
     uint4* d = reinterpret_cast<uint4*>(dict);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         uint32_t within = (uint32_t)(i % vec_per_bkt) * 16;
-        uint32_t v = within < kBktSuffixOff ? 0u : 0xFFFFFFFFu;
+        uint32_t v = within < slot_bytes ? 0u : 0xFFFFFFFFu;
         d[i] = make_uint4(v, v, v, v);
     }
 }
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(64) void k_rolz_parse_serial(ParseArgs a) {
     a.ntok[blk] = nt;
 }
 
-void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_dict_reset, dim3(2048), dim3(256), 0, s, dict, nblocks);
+void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide) {
+    hipLaunchKernelGGL(k_dict_reset, dim3(2048), dim3(256), 0, s, dict, nblocks, (wide ? 8u : 4u) * (uint32_t)kRing);
 }
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_rolz_parse_serial, dim3(nblocks - a.blk0), dim3(64), 0, s, a);
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     const int wave = threadIdx.x >> 6;
     const unsigned long long lane_bit = 1ull << lane;
     const unsigned long long below = lane_bit - 1ull, beloweq = below | lane_bit;
+    constexpr bool kWide = kAllL0;                   // slot plane form (zlng_common.h): the launcher's reset matches
 
     if (wave == 0) {
         for (int i = lane; i < 256 + 1; i += 64) { if (i < 256) heads[i] = 0; ctxtab[i] = 0; ektab[i] = 0; }
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                 Spec S;
                 const uint32_t pctx = wpp >> 24, pl1 = qap.a & 0xFF, pl2 = (qap.a >> 8) & 0xFF;
                 if (kAllL0 || (pcfg.depth == 2 && pcfg.lazy1 == 1 && pcfg.lazy2 == 0)) {
-                    speculate_l0w(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, 0u, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
+                    speculate_l0w<kWide>(S, dict, buf, heads[pctx], heads[pl1], kRiskDist, pos, qap, 0u, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 } else speculate(S, dict, buf, heads[pctx], heads[pl1], heads[pl2], kRiskDist, pos, pcfg, qap, pctx, hp % kHashSlots, (hp / kHashSlots) & 255u);
                 asm volatile("" :: "v"(S.sp), "v"(S.dmin), "v"(S.node0));
             }
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             // without room for a match (the last 275 bytes of the block) reads at most 354 bytes past the block -- the
             // next block's text or the boundary's 512 readable bytes -- and everything derived from its result is
             // gated by canm below.
-            if (level0) speculate_l0w(S, dict, buf, heads[ctx], heads[w4 & 0xFF], kRiskDist, pos, qtext, t16, ctx, hc, chk);
+            if (level0) speculate_l0w<kWide>(S, dict, buf, heads[ctx], heads[w4 & 0xFF], kRiskDist, pos, qtext, t16, ctx, hc, chk);
             else if (canm) speculate(S, dict, buf, heads[ctx], heads[w4 & 0xFF], heads[(w4 >> 8) & 0xFF], kRiskDist, pos, cfg, qtext, ctx, hc, chk);
             uint32_t sp = (level0 && !canm) ? (uint32_t)(kMatchMin - 1) : S.sp;
             const uint32_t node0 = S.node0, head0 = S.head0, dmin = S.dmin;
@@ -409,9 +411,10 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                     const uint32_t head = (rl(head0, sl) + (uint32_t)__popcll(rl64(ctxmask, sl) & acc) + 1u) & (kRing - 1);
                     if (use_spec) {                  // speculation validated by the caller: insert + speculative result
                         if (lane == sl) {
-                            Bucket B(dict, ctx);
+                            BucketT<kWide> B(dict, ctx);
                             B.suffix[head] = (uint16_t)node0w;
-                            B.slot[head] = (unsigned long long)((uint32_t)pos | chk << 24) | (unsigned long long)pword << 32;
+                            if (kWide) B.slot[head] = (unsigned long long)((uint32_t)pos | chk << 24) | (unsigned long long)pword << 32;
+                            else B.offset[head] = (uint32_t)pos | chk << 24;
                             B.hash[hc] = (uint16_t)head;
                         }
                         is_match = ((match_lanes >> sl) & 1ull) != 0;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                         midx = (int)((head - rl(mnode, sl)) & (kRing - 1));
                     } else {
                         int mi = 0, ml = 0;
-                        const bool hit = match_exact<true>(dict, buf, q, cfg, head, lane == 0, mi, ml);
+                        const bool hit = match_exact<kWide>(dict, buf, q, cfg, head, lane == 0, mi, ml);
                         is_match = __builtin_amdgcn_readfirstlane((int)hit) != 0;
                         mlen = __builtin_amdgcn_readfirstlane(ml);
                         midx = __builtin_amdgcn_readfirstlane(mi);
@@ -584,9 +587,10 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                         if (mine) {
                             uint32_t word;
                             if (canm) {
-                                Bucket B(dict, ctx);
+                                BucketT<kWide> B(dict, ctx);
                                 B.suffix[head] = (uint16_t)node0w;
-                                B.slot[head] = (unsigned long long)((uint32_t)pos | chk << 24) | (unsigned long long)pword << 32;
+                                if (kWide) B.slot[head] = (unsigned long long)((uint32_t)pos | chk << 24) | (unsigned long long)pword << 32;
+                                else B.offset[head] = (uint32_t)pos | chk << 24;
                                 // several starts of one hash slot can commit together now; the slot's head must end up
                                 // being the last of them, so a lane that is the predecessor of a later one does not write it
                                 if (head_writer) B.hash[hc] = (uint16_t)head;

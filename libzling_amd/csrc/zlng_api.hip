@@ -199,7 +199,7 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     static const int pipe_pf = getenv("ZLNG_PIPE_PF") ? atoi(getenv("ZLNG_PIPE_PF")) : 1;
     ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
                  c->tok_cap, blk0, overflow_flag(c)};
-    launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream);
+    launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, c->parser_kind == 2 && c->level == 0);
     timer_mark(c, "dict_reset");
     if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
     else if (c->parser_kind == 0) { pa.pf_ahead = pipe_lead; pa.pf_waves = pipe_pf; launch_rolz_parse_pipe(pa, nb, c->stream, c->level == 0); }

@@ -30,13 +30,14 @@ constexpr int kMaxSub = 80;
 
 // ---- HBM layout of one context's dictionary: 256 buckets x 57,344 B ------------------
 // (the reference's ZlingEncodeBucket, src/libzling_lz.h:98-103, re-laid as three planes; `head` lives in LDS
-//  during a parse.  A ring slot is 8 bytes: its own word and a copy of the word of the slot it links to, taken
-//  when the link was made -- the wave parser reads a chain's second node without a dependent load; rolz_dev.h
-//  `speculate_l0w` says when the copy is what the reference would read and what follows when it is not)
-constexpr uint32_t kBktOffsetOff = 0;                       // {u32 pos | hash_check << 24, u32 same word of the linked slot}[4096]
-constexpr uint32_t kBktSuffixOff = 8 * kRing;               // u16[4096]
-constexpr uint32_t kBktHashOff   = 8 * kRing + 2 * kRing;   // u16[8192]
-constexpr uint32_t kBktBytes     = 8 * kRing + 2 * kRing + 2 * kHashSlots;   // 57,344
+//  during a parse.)  Two forms of the slot plane, chosen per parse kernel (rolz_dev.h BucketT):
+//   compact  u32 slot = pos | hash_check << 24; planes at 0 / 16 KiB / 24 KiB, 40,960 B of the bucket used
+//            (serial and pipelined parsers, and the wave parser on a context whose level is not 0: its generic
+//            speculation walks long chains and wants the plane dense);
+//   wide     8-byte slot = own word + a copy of the word of the slot it links to, taken when the link was made:
+//            the level-0 wave parser reads a chain's second node without a dependent load (`speculate_l0w`
+//            says when the copy is what the reference would read and what follows when it is not).
+constexpr uint32_t kBktBytes     = 8 * kRing + 2 * kRing + 2 * kHashSlots;   // 57,344 (the wide form)
 constexpr size_t   kDictBytes    = (size_t)256 * kBktBytes;                  // 14,680,064 per block
 
 // ---- token word (same as oracle/zlng_oracle.h) ---------------------------------------

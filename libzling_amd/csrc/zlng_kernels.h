@@ -22,7 +22,7 @@ struct ParseArgs {
     uint32_t       blk0;        // first block of this launch (a level-schedule repair re-parses a tail of the range)
     uint32_t*      overflow;    // set to 1 by a block that ran out of token words (its output is then incomplete)
 };
-void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s);
+void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide);   // wide: the slot plane form of the level-0 wave parser
 // both parse blocks [a.blk0, nblocks)
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
 void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);
