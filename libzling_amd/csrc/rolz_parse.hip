@@ -139,8 +139,13 @@ void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t 
 // buf[e-3] and word buf[e-2..e-1], conditional after a match, unconditional after a literal or a
 // 257 word, absent after a 256 word) and applied when that lane is processed; the type of the
 // last token is carried across rounds, and dropped at a sub-block end like the reference's MRU.
+// Long matches at level 0: phase 1 compares 16 bytes per chain node and leaves a lane whose compare ran that far "open"
+// (rolz_dev.h Spec); open lanes absorb the chase's jump chains, and the one the chase actually reaches as a token start is
+// settled there (finish_open: all lanes compare 4 bytes each, one round trip) before it is validated.  Inside a long match
+// every lane of the window is long; almost none of them is a token start.
 // kAllL0: every sub-block of the batch runs at level 0 (always true for an e0 context, whose schedule cannot
-// change): the generic speculation and the level tests drop out of the kernel.
+// change): the generic speculation and the level tests drop out of the kernel, and the dictionary's slot plane takes its
+// wide form (zlng_common.h; the launcher's k_dict_reset must agree).
 // kProf: cycle counters into a.dbg (ZLNG_PROFILE=1); compiled out of the production kernels.
 template <bool kAllL0, bool kProf>
 __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
