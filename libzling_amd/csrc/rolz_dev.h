@@ -29,6 +29,22 @@ __device__ __forceinline__ int common_len(const uint8_t* a, const uint8_t* b) {
     return n;
 }
 
+// GetCommonLength for a wave-uniform pair, all 64 lanes helping: lane t compares bytes 4t .. 4t+3, lane 0 also the
+// last three (256 .. 258), one round trip instead of one per 4 bytes.  Every lane must be active and hold the same a, b.
+__device__ __forceinline__ int common_len_wave(const uint8_t* a, const uint8_t* b) {
+    const uint32_t t4 = 4u * (threadIdx.x & 63u);
+    const uint32_t x = ld32u(a + t4) ^ ld32u(b + t4);
+    const uint32_t xt = (ld32u(a + 256) ^ ld32u(b + 256)) & 0xFFFFFFu;
+    const unsigned long long m = __ballot(x != 0u);
+    if (m) {
+        const int f = (int)__builtin_ctzll(m);
+        if (f == 0) return 0;
+        return 4 * f + (__ffs((int)__builtin_amdgcn_readlane((int)x, f)) - 1) / 8;
+    }
+    const uint32_t xl = (uint32_t)__builtin_amdgcn_readfirstlane((int)xt);
+    return xl ? 256 + (__ffs((int)xl) - 1) / 8 : kMatchMax;
+}
+
 // One context's dictionary plane.  Fields are addressed as (wave-uniform base) + (32-bit byte offset): the whole
 // per-block dictionary is 10 MiB, so the offset fits a VGPR and every access is a global_load/store with an SGPR
 // base ("saddr") -- no 64-bit per-lane pointer arithmetic.
@@ -71,7 +87,8 @@ __device__ __forceinline__ bool lazy_probe(uint8_t* dict, const uint8_t* buf, in
 // `head` is the ring slot this insert takes (the caller owns the per-context head counters).
 // Safe to run wave-uniformly: every lane computes the same thing, lane 0 alone stores.
 // kCopy: the wide slot plane, the insert also stores the copy of its link's word (zlng_common.h).
-template <bool kCopy = false>
+// kWave: called by a whole wavefront with identical arguments (the wave parser's replays): the LCP is one round trip.
+template <bool kCopy = false, bool kWave = false>
 __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, int pos, const LevelCfg cfg,
                                             uint32_t head, bool writer, int& match_idx, int& match_len) {
     uint32_t h = hash4(buf + pos);
@@ -99,7 +116,7 @@ __device__ __forceinline__ bool match_exact(uint8_t* dict, const uint8_t* buf, i
         uint32_t ov = node == head ? own : (kCopy && i == 0) ? ov_first : B.offset[node];
         uint32_t off = ov & 0xFFFFFF;
         if ((ov >> 24) == chk && buf[pos + maxlen] == buf[off + maxlen]) {
-            int len = common_len(buf + pos, buf + off);
+            int len = kWave ? common_len_wave(buf + pos, buf + off) : common_len(buf + pos, buf + off);
             if (len > maxlen) { maxnode = node; maxlen = len; if (maxlen == kMatchMax) break; }
         }
         uint32_t nx = B.suffix[node];

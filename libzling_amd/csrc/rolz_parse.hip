@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                         midx = (int)((head - rl(mnode, sl)) & (kRing - 1));
                     } else {
                         int mi = 0, ml = 0;
-                        const bool hit = match_exact<kWide>(dict, buf, q, cfg, head, lane == 0, mi, ml);
+                        const bool hit = match_exact<kWide, true>(dict, buf, q, cfg, head, lane == 0, mi, ml);
                         is_match = __builtin_amdgcn_readfirstlane((int)hit) != 0;
                         mlen = __builtin_amdgcn_readfirstlane(ml);
                         midx = __builtin_amdgcn_readfirstlane(mi);
