@@ -153,7 +153,8 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *                                 by host threads (literal runs over PCIe and back) while the device walks the others.
  *                                 The product path is all-device; this mode exists because SURVEY 8(e) asks to choose by
  *                                 measurement and bench.py reports it as a separate line.
- *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py) */
+ *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py)
+ *   ZLNG_PF_AHEAD, ZLNG_PF_WAVES, ZLNG_MIN_RESTART, ZLNG_SETTLE_PF   parser tuning knobs (defaults are the measured best) */
 
 /* The hipStream_t the context launches on (as void*), for callers that need to order work. */
 void* zlng_stream(zlng_ctx*);

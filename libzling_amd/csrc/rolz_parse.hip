@@ -214,6 +214,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     uint32_t nt = 0;
     int q = 0, nsub = 0;
     bool overflow = false;
+    bool settled_prev = false;                       // the previous round settled an open lane (finish_open)
     unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
     unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0, n_fin = 0, c_fin = 0, c_finw = 0;
     const bool prof = kProf && a.dbg != nullptr;
@@ -297,6 +298,24 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             unsigned long long match_lanes = __ballot(spec_match);
             const bool is_open = level0 && canm && S.open;
             unsigned long long open_mask = __ballot(is_open);
+            // The first open lane of a window is where a long match begins: in text with many long matches nearly always
+            // a token start.  Its settling loads go out now and land behind the mask phase; finish_open uses them if the
+            // chase does stop there.  (a.settle_pf, same box, same run: real text 894 / 867 / 877 ms for never / always /
+            // only after a round that settled a lane; the benchmark text 756 / 753 / 756 -- boxes differ by +-2 %.)
+            constexpr uint32_t kOK = kOpenAt;                  // bytes already known equal
+            auto open_loads = [&](int L, uint32_t& a4, uint32_t& b4, uint32_t& c4, uint32_t& e4, uint32_t& d4) {
+                const uint32_t ol = rl(S.olen, L), offA = rl(S.off0, L), offB = rl(S.off1, L), ls = rl(S.lsrc1, L);
+                const uint32_t pL = (uint32_t)(P + L), t4 = 4u * (uint32_t)lane;
+                a4 = ld32u(buf + (pL + kOK + t4));
+                b4 = ld32u(buf + ((((ol >> 16) & 1u) ? offA : pL) + kOK + t4));
+                c4 = ld32u(buf + ((((ol >> 17) & 1u) ? offB : pL) + kOK + t4));
+                e4 = ld32u(buf + (pL + kOK - 4u + t4));                                   // lazy probe operands,
+                d4 = ld32u(buf + (((ls >> 31) ? (ls & 0xFFFFFF) : pL) + kOK - 4u + t4));  // from byte kOpenAt - 4 on
+            };
+            int pre_L = -1;
+            uint32_t pre_a = 0, pre_b = 0, pre_c = 0, pre_e = 0, pre_d = 0;
+            if (open_mask && (a.settle_pf == 1 || (a.settle_pf == 2 && settled_prev))) { pre_L = (int)__builtin_ctzll(open_mask); open_loads(pre_L, pre_a, pre_b, pre_c, pre_e, pre_d); }
+            settled_prev = false;
             // eight-token jumps for the chase: next start after 8 tokens and the starts passed on the way (three
             // doubling steps over ds_bpermute; a lone wave pays ~100 cycles per scalar hop otherwise).  The first
             // step's mask is known without a shuffle: the token after mine starts at lane n1, if that lane is live.
@@ -356,15 +375,11 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             auto finish_open = [&](int L) {
                 unsigned long long tf0 = 0;
                 if (prof) tf0 = __builtin_readcyclecounter();
-                const uint32_t ol = rl(S.olen, L), offA = rl(S.off0, L), offB = rl(S.off1, L), ls = rl(S.lsrc1, L);
+                const uint32_t ol = rl(S.olen, L), ls = rl(S.lsrc1, L);
                 const bool lg0 = ((ol >> 16) & 1u) != 0, lg1 = ((ol >> 17) & 1u) != 0, h1s = ((ol >> 18) & 1u) != 0;
-                const uint32_t pL = (uint32_t)(P + L), t4 = 4u * (uint32_t)lane;
-                constexpr uint32_t K = kOpenAt;                    // bytes already known equal
-                const uint32_t a4 = ld32u(buf + (pL + K + t4));
-                const uint32_t b4 = ld32u(buf + ((lg0 ? offA : pL) + K + t4));
-                const uint32_t c4 = ld32u(buf + ((lg1 ? offB : pL) + K + t4));
-                const uint32_t e4 = ld32u(buf + (pL + K - 4u + t4));                                   // lazy probe operands,
-                const uint32_t d4 = ld32u(buf + (((ls >> 31) ? (ls & 0xFFFFFF) : pL) + K - 4u + t4));  // from byte K - 4 on
+                constexpr uint32_t K = kOpenAt;
+                uint32_t a4 = pre_a, b4 = pre_b, c4 = pre_c, e4 = pre_e, d4 = pre_d;
+                if (L != pre_L) open_loads(L, a4, b4, c4, e4, d4);
                 uint32_t l0 = ol & 0xFF, l1 = (ol >> 8) & 0xFF;
                 if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c_finw += __builtin_readcyclecounter() - tf0; }
                 if (lg0) {
@@ -395,6 +410,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                 if (lane == L) { sp = nsp; S.len0 = l0; spec_len = ml; spec_match = nm; tlen = nm ? ml : 1u; }
                 match_lanes = (match_lanes & ~(1ull << L)) | (nm ? 1ull << L : 0ull);
                 open_mask &= ~(1ull << L);
+                settled_prev = true;
                 if (prof) { n_fin++; c_fin += __builtin_readcyclecounter() - tf0; }
             };
 

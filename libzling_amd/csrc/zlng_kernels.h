@@ -21,6 +21,8 @@ struct ParseArgs {
     uint32_t       tok_cap;     // token words reserved per block
     uint32_t       blk0;        // first block of this launch (a level-schedule repair re-parses a tail of the range)
     uint32_t*      overflow;    // set to 1 by a block that ran out of token words (its output is then incomplete)
+    int            settle_pf;   // wave parser: early loads for the first open lane of a window: 0 never, 1 always, 2 while
+                                // the previous round settled a lane (tuning, ZLNG_SETTLE_PF)
 };
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide);   // wide: the slot plane form of the level-0 wave parser
 // both parse blocks [a.blk0, nblocks)
