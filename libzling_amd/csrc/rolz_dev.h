@@ -210,6 +210,7 @@ struct Spec {
     uint32_t off0, off1, olen;
     bool open;
     uint32_t ov0;                        // node 0's slot word (the inserting lane stores it as its link's copy)
+    uint32_t lkey1;                      // exact key of the lazy probe at +1: context << 13 | hash13 (speculate_l0w)
 };
 
 __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
@@ -498,7 +499,7 @@ __device__ __forceinline__ void speculate_l0w(Spec& S, uint8_t* dict, const uint
     S.ld1 = ld1; S.ld2 = kRing - 1;
     S.lz1 = lz1; S.lz2 = false;
     S.len0 = len0; S.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u); S.qa = qa;
-    S.ov0 = ov0;
+    S.ov0 = ov0; S.lkey1 = lctx1 << 13 | hh1;
 }
 
 // Ordering point for LDS traffic inside ONE wavefront (program order is execution order for a wave's LDS

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     bool overflow = false;
     bool settled_prev = false;                       // the previous round settled an open lane (finish_open)
     unsigned long long c_p1 = 0, c_mask = 0, c_p2 = 0, n_round = 0, n_redo = 0, n_poss = 0, n_seg = 0, c_ser = 0, c_chase = 0;
-    unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0, n_fin = 0, c_fin = 0, c_finw = 0;
+    unsigned long long n_cA = 0, n_cB = 0, n_cL = 0, n_same = 0, n_replay = 0, c_val = 0, c_com = 0, n_fin = 0, c_fin = 0, c_finw = 0, n_lfix = 0;
     const bool prof = kProf && a.dbg != nullptr;
 
     while (q < ilen && !overflow) {                  // ---- one sub-block (one EncodeImpl call)
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             S.lkix1 = S.lkix2 = S.lctx1 = S.lctx2 = 0; S.lz1 = S.lz2 = false;
             S.ld1 = S.ld2 = kRing - 1;
             S.len0 = 0; S.lsrc1 = 0; S.qa = Quad{0, 0, 0, 0};
-            S.off0 = S.off1 = S.olen = 0; S.open = false; S.ov0 = 0;
+            S.off0 = S.off1 = S.olen = 0; S.open = false; S.ov0 = 0; S.lkey1 = 0;
             const uint32_t kix_w = canm ? kix : (uint32_t)kKeyTab, ctx_w = canm ? ctx : 256u;
             atomicOr(&keytab[kix_w], lane_bit);
             atomicOr(&ctxtab[ctx_w], lane_bit);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             }
 
             wsync();                         // all lane bits are in the tables
-            unsigned long long lkey = 0;
+            unsigned long long lkey = 0, lk_mask = 0, lc_mask = 0;    // (lk / lc apart: the lazy-only conflict fix, level 0)
             const unsigned long long keymask_r = keytab[kix_w], ctxmask_r = ctxtab[ctx_w];
             const unsigned long long keymask = canm ? keymask_r : 0ull, ctxmask = canm ? ctxmask_r : 0ull;
             // a lazy probe is invalidated by an accepted insert with its key, or -- if it walked near the
@@ -353,7 +353,8 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             //  and then needs a probe the speculation did not evaluate)
             if (level0) {                            // (lkix1 / lctx1 are 0 for lanes without a speculation: harmless reads)
                 const unsigned long long lk = keytab[lkix1], lc = ctxtab[lctx1];
-                lkey = canm ? (lk | ((sp & kSpRisk1) ? lc : 0ull)) : 0ull;
+                lk_mask = canm ? lk : 0ull; lc_mask = (canm && (sp & kSpRisk1)) ? lc : 0ull;
+                lkey = lk_mask | lc_mask;
             } else if (lz1) lkey |= keytab[lkix1] | ((sp & kSpRisk1) ? ctxtab[lctx1] : 0ull);
             if (lz2) lkey |= keytab[lkix2] | ((sp & kSpRisk2) ? ctxtab[lctx2] : 0ull);
             const unsigned long long hit_r = evtab[chix], same_r = ektab[ek_w];
@@ -568,7 +569,34 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
                     const uint32_t m0 = mru[ctx];
                     const bool poss = !spec_match && pos + 1 < ilen &&
                                       ((m0 & 0xFFFF) == cw || (m0 >> 16) == cw || (hitmask & all & beloweq) != 0);
-                    const unsigned long long prob = seg & __ballot(dirty || ldirty || poss);
+                    unsigned long long prob = seg & __ballot(dirty || ldirty || poss);
+                    // ---- lazy-only conflicts resolved in registers (level 0), one at a time and only when such a lane is the
+                    // first problem of the segment.  The lane's own match stands (no accepted start wrote its hash slot or a
+                    // ring entry it read) but ONE accepted start p <= lane -- its own insert included, src/libzling_lz.cpp:271
+                    // -- carries the lane-mask bit of its lazy probe's key.  If p's key is that key exactly, p's insert is the
+                    // chain head the probe sees (depth 1: the only node it looks at) and the veto is 4 bytes of text against 4
+                    // bytes of text; if it is another key (the mask table is hashed) nothing the probe read has changed.  The
+                    // lane is cleared only if the veto comes out as speculated, so the chase stays valid.
+                    if (level0 && a.lazy_fix && prob) {
+                        const unsigned long long lhit = lk_mask & all & beloweq;
+                        const bool lcand = ldirty && !dirty && !poss && (lhit & (lhit - 1ull)) == 0 && lhit != 0 && (lc_mask & all & beloweq) == 0;
+                        const unsigned long long lcm = seg & __ballot(lcand);
+                        while (prob) {
+                            const int f0 = (int)__builtin_ctzll(prob);
+                            if (!((lcm >> f0) & 1ull)) break;
+                            const int p = (int)__builtin_ctzll(rl64(lhit, f0));
+                            bool ok = true;
+                            if (rl(ctx << 13 | hc, p) == rl(S.lkey1, f0)) {
+                                const uint32_t mm = rl(spec_len, f0) - 3u;
+                                const uint32_t pr = ld32u(buf + ((uint32_t)(P + f0) + 1u + mm));
+                                const uint32_t sr = ld32u(buf + ((uint32_t)(P + p) + mm));
+                                ok = (ufl(pr) == ufl(sr)) == ((rl(sp, f0) & kSpVeto1) != 0);
+                            }
+                            if (!ok) break;
+                            prob &= ~(1ull << f0);
+                            if (prof) n_lfix++;
+                        }
+                    }
                     const int f = prob ? (int)__builtin_ctzll(prob) : 64;
                     const unsigned long long com = f >= 64 ? seg : (seg & ((1ull << f) - 1ull));
                     unsigned long long tcm = 0;
@@ -671,7 +699,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
     }
     if (prof && lane == 0) {
         unsigned long long* d = a.dbg + (size_t)blk * kDbgSlots;
-        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same; d[15] = c_val; d[16] = c_com; d[17] = n_fin; d[18] = c_fin; d[19] = c_finw;
+        d[0] = c_p1; d[1] = c_mask; d[2] = c_p2; d[3] = n_round; d[4] = nt; d[5] = n_seg; d[6] = n_redo; d[7] = n_poss; d[8] = c_ser; d[9] = c_chase; d[10] = n_cA; d[11] = n_cB; d[12] = n_cL; d[13] = n_replay; d[14] = n_same; d[15] = c_val; d[16] = c_com; d[17] = n_fin; d[18] = c_fin; d[19] = c_finw; d[20] = n_lfix;
     }
 }
 

@@ -198,8 +198,9 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     static const int pipe_lead = getenv("ZLNG_PIPE_LEAD") ? atoi(getenv("ZLNG_PIPE_LEAD")) : 2;
     static const int pipe_pf = getenv("ZLNG_PIPE_PF") ? atoi(getenv("ZLNG_PIPE_PF")) : 1;
     static const int settle_pf = getenv("ZLNG_SETTLE_PF") ? atoi(getenv("ZLNG_SETTLE_PF")) : 1;
+    static const int lazy_fix = getenv("ZLNG_LAZY_FIX") ? atoi(getenv("ZLNG_LAZY_FIX")) : 1;
     ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
-                 c->tok_cap, blk0, overflow_flag(c), settle_pf};
+                 c->tok_cap, blk0, overflow_flag(c), settle_pf, lazy_fix};
     launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, c->parser_kind == 2 && c->level == 0);
     timer_mark(c, "dict_reset");
     if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);

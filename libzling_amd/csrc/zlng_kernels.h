@@ -23,6 +23,7 @@ struct ParseArgs {
     uint32_t*      overflow;    // set to 1 by a block that ran out of token words (its output is then incomplete)
     int            settle_pf;   // wave parser: early loads for the first open lane of a window: 0 never, 1 always, 2 while
                                 // the previous round settled a lane (tuning, ZLNG_SETTLE_PF)
+    int            lazy_fix;    // wave parser, level 0: resolve lazy-only conflicts in registers (1; 0 = replay them, ZLNG_LAZY_FIX)
 };
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide);   // wide: the slot plane form of the level-0 wave parser
 // both parse blocks [a.blk0, nblocks)

@@ -45,8 +45,8 @@ if os.environ.get("ZLNG_PROFILE") == "1":
         for b in range(nb):
             d = buf[SL * b: SL * b + 24]
             r = max(d[3], 1)
-            print("blk %2d: %5.0f Mcyc  rounds %6d tokens %7d  per round p1 %5.0f mask %5.0f p2 %5.0f  settled tails %.2f/round  problem tokens %.2f/round (conflicts %.2f)  segments %.2f/round | p2 parts: chase+settle %4.0f validate %4.0f commit %4.0f serial %4.0f | per settled tail %4.0f cyc (%4.0f until the loads land)" % (
-                b, (d[0] + d[1] + d[2]) / 1e6, d[3], d[4], d[0] / r, d[1] / r, d[2] / r, d[17] / r, (d[6] + d[7]) / r, d[6] / r, d[5] / r,
+            print("blk %2d: %5.0f Mcyc  rounds %6d tokens %7d  per round p1 %5.0f mask %5.0f p2 %5.0f  settled tails %.2f/round  problem tokens %.2f/round (conflicts %.2f, lazy fixes %.2f)  segments %.2f/round | p2 parts: chase+settle %4.0f validate %4.0f commit %4.0f serial %4.0f | per settled tail %4.0f cyc (%4.0f until the loads land)" % (
+                b, (d[0] + d[1] + d[2]) / 1e6, d[3], d[4], d[0] / r, d[1] / r, d[2] / r, d[17] / r, (d[6] + d[7]) / r, d[6] / r, d[20] / r, d[5] / r,
                 d[9] / r, d[15] / r, d[16] / r, d[8] / r, d[18] / max(d[17], 1), d[19] / max(d[17], 1)))
     for b in range(min(nb, 4)):
         d = buf[SL * b: SL * b + 8]
