@@ -1,0 +1,41 @@
+"""Host-side logic of bench.py that needs no GPU: the identity of the kernel sources a PMC profile belongs to and the rule
+that a committed traffic figure is quoted only for those very sources and that very workload."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+
+def test_kernel_source_sha_is_a_stable_hash_of_the_encode_kernels():
+    a, b = bench.kernel_source_sha(), bench.kernel_source_sha()
+    assert a == b and len(a) == 16 and int(a, 16) >= 0
+    for f in bench.ENCODE_KERNEL_SOURCES:
+        assert os.path.exists(os.path.join(ROOT, "libzling_amd", "csrc", f)), f
+
+
+def test_traffic_is_quoted_only_for_the_same_sources_and_workload(tmp_path, monkeypatch):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    entry = {"kernel_source_sha": "0" * 16, "workload": {"bytes": 1000, "level": 0, "blocks": 1},
+             "kernels": {"k_rolz_parse_wave": {"hbm_bytes_corrected": 4242}}}
+    (prof / "r09_z_pmc_traffic.json").write_text(json.dumps(entry))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "f" * 16)
+    t, src = bench.traffic_of("k_rolz_parse_wave", 1000, 0, "synthetic", 1)
+    assert t is None and src.startswith("stale")                      # other kernel sources
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "0" * 16)
+    t, src = bench.traffic_of("k_rolz_parse_wave", 1000, 0, "synthetic", 1)
+    assert t == 4242 and "r09_z_pmc_traffic.json" in src
+    assert bench.traffic_of("k_rolz_parse_wave", 2000, 0, "synthetic", 1) == (None, None)     # another size
+    assert bench.traffic_of("k_rolz_parse_wave", 1000, 4, "synthetic", 1) == (None, None)     # another level
+    assert bench.traffic_of("k_rolz_parse_wave", 1000, 0, "synthetic", 2) == (None, None)     # several ranks
+
+
+def test_the_committed_profile_of_this_round_matches_the_tree():
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+    newest = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+    assert newest["kernel_source_sha"] == bench.kernel_source_sha(), \
+        "profiles/%s was taken on other kernel sources: re-run scripts/profile_round.sh" % files[-1]
