@@ -154,7 +154,12 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *                                 The product path is all-device; this mode exists because SURVEY 8(e) asks to choose by
  *                                 measurement and bench.py reports it as a separate line.
  *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py)
- *   ZLNG_PF_AHEAD, ZLNG_PF_WAVES, ZLNG_MIN_RESTART, ZLNG_SETTLE_PF   parser tuning knobs (defaults are the measured best) */
+ *   ZLNG_PF_AHEAD, ZLNG_PF_WAVES, ZLNG_MIN_RESTART, ZLNG_SETTLE_PF, ZLNG_LAZY_FIX   parser tuning knobs (defaults are the
+ *                                 measured best); ZLNG_PIPE_LEAD, ZLNG_PIPE_PF: the same for ZLNG_PARSER=pipe
+ *   ZLNG_DEBUG_PACK_LDS=<bytes>   extra dynamic LDS for the bit packer's launch (occupancy experiments)
+ * (The C++ shim reads ZLNG_DEVICE, ZLNG_DEVICES, ZLNG_BATCH_BLOCKS and ZLNG_PIPELINE: INTEGRATION.md.  The build reads
+ *  ZLNG_HIPCC_FLAGS and ZLNG_BUILD_FORCE (__graft_entry__.py); bench.py reads ZLNG_ENWIK9 / ZLNG_ENWIK8 (a real enwik file
+ *  to use instead of the generator) and ZLNG_BENCH_ONE_DEVICE (all ranks on device 0, collectives over gloo: a test hook).) */
 
 /* The hipStream_t the context launches on (as void*), for callers that need to order work. */
 void* zlng_stream(zlng_ctx*);

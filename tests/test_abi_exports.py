@@ -67,3 +67,20 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
     assert e.value.code == -4                                   # ZLNG_E_DEVICE
     with pytest.raises(zl.ZlngError):
         zl.encode(b"hello")
+
+
+def test_every_environment_variable_read_by_the_sources_is_documented():
+    """include/zlng.h (or INTEGRATION.md for the C++ shim's) names every ZLNG_* variable the library, the shim, the tools,
+    the build and bench.py read."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    used = set()
+    for pat in ("libzling_amd/csrc/*.hip", "libzling_amd/csrc/*.h", "libzling_amd/cxx/*.cpp", "tools/*.cpp"):
+        for f in glob.glob(os.path.join(root, pat)):
+            used |= set(re.findall(r'getenv\("(ZLNG_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in ("bench.py", "__graft_entry__.py", "libzling_amd/__init__.py"):
+        used |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(ZLNG_[A-Z0-9_]+)"', open(os.path.join(root, f)).read()))
+    docs = open(os.path.join(root, "include", "zlng.h")).read() + open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(v for v in used if v not in docs)
+    assert not missing, missing
