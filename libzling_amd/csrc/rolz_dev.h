@@ -287,21 +287,32 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
 
     uint32_t maxlen = kMatchMin - 1, maxnode = 0, node = node0, dmin = kRing - 1;
     bool active = node0 != 65535u;
+    // The walk is software-pipelined: a hop costs one round trip (a node's compare block together with both ring fields
+    // of its successor), and the NEXT hop's round trip is requested before this node's bytes are compared -- the ≈70
+    // instructions of a node (LCP, best-of, chain-end tests under exec masks) run while it is in flight.  The request
+    // cannot know yet whether this node ends the walk with a maximum-length match; one set of loads may go unused.
+    uint32_t off = ov & 0xFFFFFF;
+    bool cmp = active && (ov >> 24) == chk;
+    Quad qb = ld128u(buf + (cmp ? off : (uint32_t)pos));
+    uint32_t nov = B.offset[nx & (kRing - 1)];
+    uint32_t nnx = B.suffix[nx & (kRing - 1)];
     for (int i = 0; i < cfg.depth && __any(active); i++) {                 // src/libzling_lz.cpp:240-267
         if (active) dmin = min(dmin, ring_dist(node, head0));
-        const uint32_t off = ov & 0xFFFFFF;
-        const bool cmp = active && (ov >> 24) == chk;
-        const Quad qb = ld128u(buf + (cmp ? off : (uint32_t)pos));
-        const uint32_t nov = B.offset[nx & (kRing - 1)];
-        const uint32_t nnx = B.suffix[nx & (kRing - 1)];
+        const uint32_t off_n = nov & 0xFFFFFF;
+        const bool more = active && nx != 65535u && !(off <= off_n);
+        const bool cmp_n = more && (nov >> 24) == chk;
+        const Quad qb_n = ld128u(buf + (cmp_n ? off_n : (uint32_t)pos));
+        const uint32_t nov_n = B.offset[nnx & (kRing - 1)];
+        const uint32_t nnx_n = B.suffix[nnx & (kRing - 1)];
         uint32_t len = cmp ? lcp16(qa, qb) : 0u;
         const bool lng = cmp && len == 16u;
         if (__any(lng)) { const uint32_t t = lcp_tail(buf + pos, buf + off, lng); len = lng ? t : len; }
         if (len > maxlen) { maxlen = len; maxnode = node; }
         active = active && maxlen != (uint32_t)kMatchMax && nx != 65535u;
         if (active) dmin = min(dmin, ring_dist(nx, head0));
-        active = active && !(off <= (nov & 0xFFFFFF));
+        active = active && !(off <= off_n);
         node = nx; ov = nov; nx = nnx;
+        off = off_n; cmp = active && cmp_n; qb = qb_n; nov = nov_n; nnx = nnx_n;
     }
     uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
     const bool lz = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
