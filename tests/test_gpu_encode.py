@@ -362,3 +362,20 @@ print("ok")
     env = dict(os.environ, ZLNG_HOST_RANK_CONTEXTS="3")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+@pytest.mark.parametrize("level", [0, 4])
+def test_long_matches_across_a_block_end(zl, oracle, level):
+    """Maximum-length matches up to the very end of a block and in a short block behind it: every window lane is "open"
+    (its 16-byte compare ran through), the lanes near the block end have no room for a match (no sentinel), and the chain of
+    settled lanes crosses into them.  A 1,000-byte period with a few edits, 16 MiB + 5,000 bytes; and all zeros, 17 MiB."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    unit = rng.integers(97, 123, 1000, dtype=np.uint8)
+    x = np.tile(unit, (zl.BLOCK + 5000) // 1000 + 1)[: zl.BLOCK + 5000].copy()
+    for o in rng.integers(0, x.size, 200):
+        x[o] ^= 1
+    x[zl.BLOCK - 300: zl.BLOCK - 280] = 33            # a run that ends inside the last 275 bytes of block 0
+    for data in (x, np.zeros(17 << 20, np.uint8)):
+        z = zl.encode(data, level)
+        ref = oracle.encode(data, level)
+        assert z.size == ref.size and np.array_equal(z, ref)
