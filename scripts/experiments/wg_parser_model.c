@@ -1,0 +1,445 @@
+/*
+ * wg_parser_model.c -- CPU model of the workgroup-wide ROLZ parser (libzling_amd/csrc/rolz_wg.hip).
+ *
+ * TEST / DESIGN INFRASTRUCTURE (not product code): it includes the oracle's source to reuse its dictionary and
+ * exact match functions, runs the window algorithm of the kernel lane by lane in plain loops, and compares every
+ * sub-block's tokens with the oracle's parse (zo_parse_subblock = EncodeImpl, src/libzling_lz.cpp:139-195).
+ * It exists to validate the exactness rules of the window algorithm (what a lane may decide in parallel, what makes
+ * it "hard") and to predict rounds / iterations / hard lanes per window size before a GPU is involved.
+ *
+ *   gcc -O2 -o /tmp/wgm scripts/experiments/wg_parser_model.c && /tmp/wgm FILE [NL=256] [level=0] [fix=1] [max_bytes]
+ *
+ * The window algorithm (one round, NL lanes, lane g <-> position P + g, P = the next token start):
+ *   phase 1   every lane evaluates its position AS IF it were a token start against the dictionary as of the start
+ *             of the round (read only): hash head, <= depth chain nodes, longest match, lazy probes.
+ *   iterate   S = the token starts reached from lane 0 under the current per-lane token lengths;
+ *             E(g, S): every lane re-evaluates its token given the accepted starts before it:
+ *               - word-MRU outcome: the two MRU slots of its context after every boundary event of S up to g
+ *                 (events and their effectiveness follow from the token types of S, all lane-parallel);
+ *               - its match stands unless an accepted earlier start wrote what it read (same (ctx, hash13), a ring
+ *                 slot it visited, or a lazy probe's read set): with fix = 1 same-key and lazy-key conflicts at
+ *                 level 0 are evaluated exactly from the window's text, everything else makes the lane HARD;
+ *             until no lane of S changed.  The first hard lane of S (or the sub-block's end) cuts the round.
+ *   commit    S below the cut: dictionary inserts, token words, MRU slots.  A hard lane is then replayed by the exact
+ *             serial code (MatchAndUpdate as written).
+ * At the fixed point every lane of S was evaluated under exactly the accepted starts the reference has made by then,
+ * so the result is the reference's; each iteration fixes at least the first wrong lane.
+ */
+#include "../../oracle/zlng_oracle.c"
+#include <stdio.h>
+
+enum { TY_NONE = 0, TY_LIT = 1, TY_W0 = 2, TY_W1 = 3, TY_MATCH = 4 };
+#define MAXNL 2048
+
+typedef struct {
+    int live, canm, pos;
+    uint32_t ctx, hc, chk, key, cw, ek, ew, b0;
+    /* speculation */
+    int sp_match, sp_len, sp_node, node0, head0, dmin, sp_veto;
+    uint32_t ov0;
+    uint32_t lkey[2]; int lctx[2], lrisk[2], lwant[2], ld[2];
+    int d0, d1, has1;
+    int len0;              /* level 0: candidate length of chain node 0 alone (0 if its check byte differs) */
+    int has0;
+    int lsrc1_valid; uint32_t lsrc1;   /* level 0: the lazy probe's chain head (snapshot): source offset */
+    /* iteration state */
+    int ty, tlen, mlen, mnode_slot;   /* mnode_slot: ring slot of the match source; -1 - lane if it is an in-window lane */
+    int link_lane;                    /* in-window predecessor in the hash slot (fix), -1 = snapshot node0 */
+    int ty2, tlen2, mlen2, mnode2, link2, hard, hardcls;
+    int has_ev, cond, eff; uint32_t s0b;
+} lane_t;
+
+static struct {
+    long rounds, tokens, iters, hard[8], serial, committed, cut_rounds, fixes, lfixes, maxit;
+    long hist_it[16];
+} st;
+
+static int precise_risk = 1;
+static int ring_dist(int node, int head0) { return (node - head0 - 1) & (ZO_RING - 1); }
+
+/* Read-only evaluation of `pos` as a token start against the dictionary as it is now (phase 1). */
+static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth, int lazy1, int lazy2, int risk_dist, lane_t* o) {
+    uint32_t h = hash4(buf + pos), chk = (h / ZO_HASH) % 256, hc = h % ZO_HASH;
+    const zo_bucket* b = &s->bucket[buf[pos - 1]];
+    int node = b->hash[hc], head0 = b->head, dmin = ZO_RING - 1;
+    o->node0 = node; o->head0 = head0; o->ov0 = node != 65535 ? b->offset[node] : 0; o->has0 = node != 65535;
+    o->len0 = 0; o->d0 = o->d1 = ZO_RING - 1; o->has1 = 0;
+    int maxlen = ZO_MATCH_MIN - 1, maxnode = 0;
+    if (node != 65535) {
+        for (int i = 0; i < depth; i++) {
+            int d = ring_dist(node, head0); if (d < dmin) dmin = d;
+            if (i == 0) o->d0 = d;
+            uint32_t off = b->offset[node] & 0xFFFFFF;
+            if ((b->offset[node] >> 24) == chk && buf[pos + maxlen] == buf[off + maxlen]) {
+                int len = common_len(buf + pos, buf + off);
+                if (len > maxlen) { maxnode = node; maxlen = len; }
+            }
+            if (i == 0) o->len0 = ((b->offset[node] >> 24) == chk) ? common_len(buf + pos, buf + off) : 0;
+            if (maxlen == ZO_MATCH_MAX) break;
+            int nx = b->suffix[node];
+            if (nx == 65535) break;
+            d = ring_dist(nx, head0); if (d < dmin) dmin = d;        /* its offset is read for the chain-end test */
+            if (i == 0) { o->d1 = d; o->has1 = 1; }
+            if (off <= (b->offset[nx] & 0xFFFFFF)) break;
+            node = nx;
+        }
+    }
+    o->dmin = dmin; o->sp_len = maxlen; o->sp_node = maxnode;
+    int veto = 0;
+    const int lz = maxlen >= ZO_MATCH_MIN && maxlen < ZO_LAZY_LIMIT;
+    const int ldepth[2] = {lazy1, lazy2};
+    for (int j = 0; j < 2; j++) {
+        o->lwant[j] = ldepth[j] > 0; o->lrisk[j] = 0; o->lkey[j] = 0; o->lctx[j] = 0;
+        if (!ldepth[j]) continue;
+        const int pp = pos + 1 + j;
+        const zo_bucket* lb = &s->bucket[buf[pp - 1]];
+        uint32_t hh = hash4(buf + pp) % ZO_HASH;
+        o->lctx[j] = buf[pp - 1]; o->lkey[j] = (uint32_t)buf[pp - 1] << 13 | hh;
+        int n = lb->hash[hh], ld = ZO_RING - 1;
+        if (j == 0) { o->lsrc1_valid = n != 65535; o->lsrc1 = n != 65535 ? (lb->offset[n] & 0xFFFFFF) : 0; }
+        if (n != 65535 && lz) {
+            int m = maxlen - 3;
+            for (int i = 0; i < ldepth[j]; i++) {
+                int d = ring_dist(n, lb->head); if (d < ld) ld = d;
+                uint32_t off = lb->offset[n] & 0xFFFFFF;
+                if (le32(buf + pp + m) == le32(buf + off + m)) { veto = 1; break; }
+                int nx = lb->suffix[n];
+                if (nx == 65535) break;
+                d = ring_dist(nx, lb->head); if (d < ld) ld = d;
+                if (off <= (lb->offset[nx] & 0xFFFFFF)) break;
+                n = nx;
+            }
+        } else if (n != 65535) { int d = ring_dist(n, lb->head); if (d < ld) ld = d; }   /* (level-0 fix may need the probe later) */
+        o->lrisk[j] = ld < risk_dist; o->ld[j] = ld;
+    }
+    o->sp_veto = veto;
+    o->sp_match = maxlen >= ZO_MATCH_MIN && !(lz && veto);
+}
+
+/* the exact serial token of EncodeImpl at *ipos (used for hard lanes) */
+static uint32_t serial_token(zo_stream* s, const uint8_t* ibuf, int ilen, int* ipos_, int* opos_, uint16_t mru[256][2],
+                             int depth, int lazy1, int lazy2, int* ty_out) {
+    int ipos = *ipos_, midx, mlen;
+    uint32_t word;
+    if (ipos + ZO_SENTINEL < ilen && match_and_update(s, ibuf, ipos, depth, lazy1, lazy2, &midx, &mlen)) {
+        word = (uint32_t)(258 + mlen - ZO_MATCH_MIN) | (uint32_t)midx << 16;
+        *opos_ += 2; ipos += mlen;
+        uint16_t w = (uint16_t)(ibuf[ipos - 2] << 8 | ibuf[ipos - 1]);
+        uint16_t* m = mru[ibuf[ipos - 3]];
+        if (m[0] != w) { m[1] = m[0]; m[0] = w; }
+        *ty_out = TY_MATCH;
+    } else {
+        int done = 0;
+        word = 0;
+        if (ipos + 1 < ilen) {
+            uint16_t w = (uint16_t)(ibuf[ipos] << 8 | ibuf[ipos + 1]);
+            uint16_t* m = mru[ibuf[ipos - 1]];
+            if (m[0] == w) { word = 256; (*opos_)++; ipos += 2; done = 1; *ty_out = TY_W0; }
+            else if (m[1] == w) { word = 257; (*opos_)++; ipos += 2; m[1] = m[0]; m[0] = w; done = 1; *ty_out = TY_W1; }
+        }
+        if (!done) {
+            word = (uint32_t)ibuf[ipos] | (uint32_t)ibuf[ipos - 1] << 16;
+            (*opos_)++; ipos++;
+            uint16_t* m = mru[ibuf[ipos - 3]];
+            m[1] = m[0]; m[0] = (uint16_t)(ibuf[ipos - 2] << 8 | ibuf[ipos - 1]);
+            *ty_out = TY_LIT;
+        }
+    }
+    *ipos_ = ipos;
+    return word;
+}
+
+/* NOTE on MRU bookkeeping: the model keeps `mru` in the reference's convention (pushes applied right after a token).
+ * The window algorithm attaches the push to the NEXT token start ("boundary event"); the state the window sees at its
+ * start, mru0, is the reference state with the push that follows the last token still pending, described by prevty. */
+
+static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int level, int NL, int fix, uint32_t* tok_out, int* cuts, int* ncut) {
+    const int depth = k_level_cfg[level][0], lazy1 = k_level_cfg[level][1], lazy2 = k_level_cfg[level][2];
+    static lane_t L[MAXNL];
+    static uint8_t S[MAXNL + 300];
+    int q = 0, nt = 0, nsub = 0;
+    zo_reset_buckets(s);
+    while (q < ilen) {
+        uint16_t mru[256][2];            /* window convention: state BEFORE the pending boundary event of prevty */
+        memset(mru, 0, sizeof mru);
+        int opos = 0, prevty = TY_NONE;
+        const int tok_begin = nt;
+        if (q == 0) { tok_out[nt++] = ibuf[0] | ZO_TOK_RAWCTX << 16; q = 1; opos = 1;
+                      if (ilen > 1) { tok_out[nt++] = ibuf[1] | ZO_TOK_RAWCTX << 16; q = 2; opos = 2; } }
+        int force_serial = 0;
+        while (q < ilen && opos + 1 < ZO_SUBBLOCK_SYMS) {
+            if (force_serial) {
+                /* exact serial token; the pending boundary event is applied first (window convention -> reference convention) */
+                force_serial = 0;
+                if (prevty != TY_NONE && prevty != TY_W0) {
+                    const uint32_t ek = ibuf[q - 3]; const uint16_t ew = (uint16_t)(ibuf[q - 2] << 8 | ibuf[q - 1]);
+                    if (prevty == TY_MATCH) { if (mru[ek][0] != ew) { mru[ek][1] = mru[ek][0]; mru[ek][0] = ew; } }
+                    else { mru[ek][1] = mru[ek][0]; mru[ek][0] = ew; }
+                }
+                /* serial_token applies the reference's push after the token; undo that by keeping a copy and re-deriving:
+                 * simpler: let it push, and mark prevty = NONE-equivalent "already applied" */
+                int ty;
+                uint16_t before[256][2]; memcpy(before, mru, sizeof mru);
+                tok_out[nt++] = serial_token(s, ibuf, ilen, &q, &opos, mru, depth, lazy1, lazy2, &ty);
+                /* back to the window convention: state before the push of this token; W1's own swap (m[1]=m[0]; m[0]=w) IS
+                 * that push with key ibuf[q-3] -- in both conventions the event is "after W1: unconditional push" */
+                memcpy(mru, before, sizeof mru);
+                prevty = ty;
+                st.serial++;
+                continue;
+            }
+            const int P = q;
+            const int nlive = ilen - P < NL ? ilen - P : NL;
+            /* ---- lane setup + phase 1 */
+            for (int g = 0; g < nlive; g++) {
+                lane_t* l = &L[g];
+                memset(l, 0, sizeof *l);
+                const int pos = P + g;
+                l->pos = pos; l->live = 1; l->canm = pos + ZO_SENTINEL < ilen;
+                l->ctx = ibuf[pos - 1];
+                uint32_t w4 = 0; { uint8_t t[4] = {0, 0, 0, 0}; for (int k = 0; k < 4 && pos + k < ilen + 0; k++) t[k] = ibuf[pos + k]; memcpy(&w4, t, 4); }
+                uint32_t h = w4 + ((w4 >> 16) & 0xFF) * 137u + (w4 >> 24) * 13337u;
+                l->hc = h % ZO_HASH; l->chk = (h / ZO_HASH) % 256; l->key = l->ctx << 13 | l->hc;
+                l->b0 = w4 & 0xFF;
+                l->cw = (w4 & 0xFF) << 8 | ((w4 >> 8) & 0xFF);
+                l->ek = pos >= 3 ? ibuf[pos - 3] : 0;
+                l->ew = (uint32_t)(pos >= 2 ? ibuf[pos - 2] : 0) << 8 | ibuf[pos - 1];
+                if (l->canm) speculate(s, ibuf, pos, depth, lazy1, lazy2, NL, l);
+                else { l->sp_match = 0; l->sp_len = 3; l->dmin = ZO_RING - 1; }
+                l->ty = l->sp_match ? TY_MATCH : TY_LIT;
+                l->mlen = l->sp_len; l->tlen = l->sp_match ? l->sp_len : 1;
+                l->mnode_slot = l->sp_node; l->link_lane = -1;
+            }
+            /* ---- iterate to the fixed point */
+            int limit = nlive, limit_is_hard = 0, it = 0;
+            for (;; it++) {
+                memset(S, 0, (size_t)nlive + 1);
+                for (int g = 0; g < nlive; g += L[g].tlen) S[g] = 1;
+                /* E step A: previous token type, events */
+                int prev = -1;
+                for (int g = 0; g < nlive; g++) {
+                    lane_t* l = &L[g];
+                    const int pty = prev < 0 ? prevty : L[prev].ty;
+                    l->has_ev = pty == TY_MATCH || pty == TY_LIT || pty == TY_W1;
+                    l->cond = pty == TY_MATCH;
+                    if (S[g]) prev = g;
+                }
+                /* E step B: slot 0 before each event, effectiveness (lanes of S only are events) */
+                for (int g = 0; g < nlive; g++) {
+                    lane_t* l = &L[g];
+                    int e = -1;
+                    for (int k = g - 1; k >= 0; k--) if (S[k] && L[k].has_ev && L[k].ek == l->ek) { e = k; break; }
+                    l->s0b = e >= 0 ? L[e].ew : mru[l->ek][0];
+                    l->eff = l->has_ev && (!l->cond || l->ew != l->s0b);
+                }
+                /* E step C: match validity / exact in-window evaluation, MRU check, new type */
+                for (int g = 0; g < nlive; g++) {
+                    lane_t* l = &L[g];
+                    int k = 0, a1 = -1, a2 = -1;
+                    for (int j = g - 1; j >= 0; j--) if (S[j] && L[j].canm) {
+                        if (L[j].ctx == l->ctx) k++;
+                        if (L[j].key == l->key) { if (a1 < 0) a1 = j; else if (a2 < 0) a2 = j; }
+                    }
+                    l->hard = 0; l->hardcls = 0;
+                    int is_match = 0, mlen = 3, mnode = 0, link = -1;
+                    if (l->canm) {
+                        const int ring = l->dmin <= k;
+                        /* lazy read sets: accepted starts <= g (own insert included, src/libzling_lz.cpp:271) */
+                        int lconf[2] = {0, 0}, lhit[2] = {-1, -1}, lhits[2] = {0, 0};
+                        for (int j2 = 0; j2 < 2; j2++) if (l->lwant[j2]) {
+                            int cnt = 0;
+                            for (int j = g; j >= 0; j--) if (S[j] || j == g) if (L[j].canm) {
+                                if (L[j].key == l->lkey[j2]) { if (lhit[j2] < 0) lhit[j2] = j; lhits[j2]++; }
+                                if ((int)L[j].ctx == l->lctx[j2]) cnt++;
+                            }
+                            lconf[j2] = precise_risk ? cnt > l->ld[j2] : (l->lrisk[j2] && cnt > 0);   /* a visited ring slot at distance d is rewritten by the (d+1)-th insert */
+                        }
+                        const int ring0 = l->has0 && l->d0 <= k, ring1 = l->has1 && l->d1 <= k;
+                        const int lvl0fix = fix && level == 0;
+                        if (lvl0fix ? (a1 >= 0 ? (a2 < 0 && ring0) : ring0) : ring) { l->hard = 1; l->hardcls = 2; }
+                        else if (lvl0fix && a1 < 0 && ring1) {
+                            /* node 1's slot was rewritten by a start of this round: it now holds a later position than node 0's,
+                             * so the reference's chain-end test (src/libzling_lz.cpp:265) stops the walk after node 0 */
+                            mlen = l->len0 > 3 ? l->len0 : 3; mnode = l->node0; is_match = mlen >= ZO_MATCH_MIN; st.fixes++;
+                        }
+                        else if (a1 >= 0) {
+                            if (fix && level == 0) {
+                                /* chain = [a1, a2 | node0] (depth 2): exact from the window's text */
+                                const uint8_t* p = ibuf + l->pos;
+                                int l1 = L[a1].chk == l->chk ? common_len(p, ibuf + L[a1].pos) : 0;
+                                int l2, n2;
+                                if (a2 >= 0) { l2 = L[a2].chk == l->chk ? common_len(p, ibuf + L[a2].pos) : 0; n2 = -1 - a2; }
+                                else { l2 = l->has0 ? l->len0 : 0; n2 = l->node0; }
+                                mlen = 3; mnode = 0;
+                                if (l1 > mlen) { mlen = l1; mnode = -1 - a1; }
+                                if (mlen != ZO_MATCH_MAX && (a2 >= 0 || l->has0) && l2 > mlen) { mlen = l2; mnode = n2; }
+                                link = a1;
+                                is_match = mlen >= ZO_MATCH_MIN;
+                                st.fixes++;
+                            } else { l->hard = 1; l->hardcls = 1; }
+                        } else { is_match = l->sp_len >= ZO_MATCH_MIN; mlen = l->sp_len; mnode = l->sp_node; }
+                        if (!l->hard && is_match && mlen < ZO_LAZY_LIMIT) {
+                            /* lazy probes under mlen */
+                            int veto = 0, need_hard = 0;
+                            for (int j2 = 0; j2 < 2 && !veto; j2++) if (l->lwant[j2]) {
+                                const int conflict = lhit[j2] >= 0 || lconf[j2];
+                                if (!conflict && mlen == l->sp_len) { /* speculative probe stands */
+                                    /* per-probe veto is not kept apart in the model: recompute on the snapshot (read-only, exact) */
+                                    veto = lazy_probe(s, ibuf, l->pos + 1 + j2, mlen, j2 == 0 ? lazy1 : lazy2);
+                                } else if (fix && level == 0 && !lconf[j2]) {
+                                    /* depth-1 probe: the chain head is the newest accepted start with the probe's key, else the snapshot's */
+                                    const int m = mlen - 3, pp = l->pos + 1;
+                                    if (lhit[j2] >= 0) { veto = le32(ibuf + pp + m) == le32(ibuf + L[lhit[j2]].pos + m); st.lfixes++; }
+                                    else veto = l->lsrc1_valid && le32(ibuf + pp + m) == le32(ibuf + l->lsrc1 + m);
+                                } else { need_hard = 1; break; }
+                            }
+                            if (need_hard) { l->hard = 1; l->hardcls = 3; }
+                            else if (veto) is_match = 0;
+                        }
+                    }
+                    if (l->hard) { l->ty2 = l->ty; l->tlen2 = l->tlen; l->mlen2 = l->mlen; l->mnode2 = l->mnode_slot; l->link2 = l->link_lane; continue; }
+                    if (is_match) { l->ty2 = TY_MATCH; l->tlen2 = mlen; l->mlen2 = mlen; l->mnode2 = mnode; l->link2 = link; continue; }
+                    l->link2 = link; l->mlen2 = 3; l->mnode2 = 0;
+                    /* word MRU: slots of my context after every event of S at boundaries <= g */
+                    int ty = TY_LIT;
+                    if (l->pos + 1 < ilen) {
+                        int e1 = -1, e2 = -1;
+                        for (int j = g; j >= 0; j--) if ((S[j] || j == g) && L[j].has_ev && L[j].ek == l->ctx) {
+                            if (j == g && !S[g]) { /* g evaluated as a hypothetical start: its own event counts */ }
+                            if (e1 < 0) e1 = j;
+                            if (e2 < 0 && L[j].eff) e2 = j;
+                            if (e1 >= 0 && e2 >= 0) break;
+                        }
+                        const uint32_t s0 = e1 >= 0 ? L[e1].ew : mru[l->ctx][0];
+                        const uint32_t s1 = e2 >= 0 ? L[e2].s0b : mru[l->ctx][1];
+                        if (s0 == l->cw) ty = TY_W0; else if (s1 == l->cw) ty = TY_W1;
+                    }
+                    l->ty2 = ty; l->tlen2 = ty == TY_LIT ? 1 : 2;
+                }
+                /* cut of the round: first hard lane of S, or the sub-block's end */
+                limit = nlive; limit_is_hard = 0;
+                { int sym = 0;
+                  for (int g = 0; g < nlive; g++) if (S[g]) {
+                      if (!(opos + sym + 1 < ZO_SUBBLOCK_SYMS)) { limit = g; break; }
+                      if (L[g].hard) { limit = g; limit_is_hard = 1; break; }
+                      sym += L[g].ty2 == TY_MATCH ? 2 : 1;
+                  } }
+                int changed = 0;
+                for (int g = 0; g < limit; g++) if (S[g]) {
+                    lane_t* l = &L[g];
+                    if (l->ty2 != l->ty || l->tlen2 != l->tlen) changed = 1;
+                }
+                /* (a lane whose match source / link changed but not its length: S is unchanged, later lanes saw the same S) */
+                for (int g = 0; g < nlive; g++) { lane_t* l = &L[g]; l->ty = l->ty2; l->tlen = l->tlen2; l->mlen = l->mlen2; l->mnode_slot = l->mnode2; l->link_lane = l->link2; }
+                if (!changed) break;
+                if (it > 4 * NL) { fprintf(stderr, "no convergence at P=%d\n", P); return -1; }
+            }
+            st.rounds++; st.iters += it + 1; st.hist_it[it < 15 ? it : 15]++; if (it + 1 > st.maxit) st.maxit = it + 1;
+            /* ---- commit S below the limit (sequentially here; the formulas are the kernel's) */
+            uint16_t mru_seq[256][2]; memcpy(mru_seq, mru, sizeof mru);     /* sequential emulation of the events, for the assert */
+            int slot_of[MAXNL];
+            int ncom = 0, last = -1;
+            for (int g = 0; g < limit; g++) if (S[g]) {
+                lane_t* l = &L[g];
+                /* events, sequential emulation */
+                if (l->has_ev) {
+                    if (l->cond) { if (mru_seq[l->ek][0] != l->ew) { mru_seq[l->ek][1] = mru_seq[l->ek][0]; mru_seq[l->ek][0] = (uint16_t)l->ew; } }
+                    else { mru_seq[l->ek][1] = mru_seq[l->ek][0]; mru_seq[l->ek][0] = (uint16_t)l->ew; }
+                }
+                /* check the parallel MRU outcome against the sequential state */
+                if (l->ty != TY_MATCH) {
+                    int want = TY_LIT;
+                    if (l->pos + 1 < ilen) { if (mru_seq[l->ctx][0] == l->cw) want = TY_W0; else if (mru_seq[l->ctx][1] == l->cw) want = TY_W1; }
+                    if (want != l->ty) { fprintf(stderr, "MRU formula mismatch at pos %d: %d vs %d\n", l->pos, l->ty, want); return -1; }
+                }
+                uint32_t word;
+                if (l->canm) {
+                    zo_bucket* b = &s->bucket[l->ctx];
+                    int k = 0; for (int j = 0; j < g; j++) if (S[j] && L[j].canm && L[j].ctx == l->ctx) k++;
+                    const int head = (l->head0 + k + 1) & (ZO_RING - 1);
+                    b->head = (uint16_t)((b->head + 1) & (ZO_RING - 1));
+                    if (b->head != head) { fprintf(stderr, "head formula mismatch\n"); return -1; }
+                    slot_of[g] = head;
+                    const int link = l->link_lane >= 0 ? slot_of[l->link_lane] : l->node0;
+                    if (b->hash[l->hc] != link) { fprintf(stderr, "link mismatch at pos %d: hash head %d, link %d\n", l->pos, b->hash[l->hc], link); return -1; }
+                    b->suffix[head] = (uint16_t)link; b->offset[head] = (uint32_t)l->pos | l->chk << 24; b->hash[l->hc] = (uint16_t)head;
+                    if (l->ty == TY_MATCH) {
+                        const int mn = l->mnode_slot < 0 ? slot_of[-1 - l->mnode_slot] : l->mnode_slot;
+                        word = (uint32_t)(258 + l->mlen - ZO_MATCH_MIN) | (uint32_t)((head - mn) & (ZO_RING - 1)) << 16;
+                    } else word = 0;
+                } else word = 0;
+                if (l->ty == TY_W0) word = 256; else if (l->ty == TY_W1) word = 257; else if (l->ty == TY_LIT) word = l->b0 | l->ctx << 16;
+                tok_out[nt++] = word;
+                opos += l->ty == TY_MATCH ? 2 : 1;
+                ncom++; last = g;
+            }
+            /* final MRU state by the kernel's formula: per key, the last event lane writes (s0, s1) */
+            for (int g = 0; g < limit; g++) if (S[g] && L[g].has_ev) {
+                lane_t* l = &L[g];
+                int later = 0; for (int j = g + 1; j < limit; j++) if (S[j] && L[j].has_ev && L[j].ek == l->ek) later = 1;
+                if (later) continue;
+                int e2 = -1; for (int j = g; j >= 0; j--) if (S[j] && L[j].eff && L[j].ek == l->ek) { e2 = j; break; }
+                mru[l->ek][0] = (uint16_t)l->ew; mru[l->ek][1] = e2 >= 0 ? (uint16_t)L[e2].s0b : mru[l->ek][1];
+            }
+            if (memcmp(mru, mru_seq, sizeof mru)) { fprintf(stderr, "final MRU formula mismatch in round at %d\n", P); return -1; }
+            st.committed += ncom;
+            if (last >= 0) { q = L[last].pos + L[last].tlen; prevty = L[last].ty; }
+            if (limit_is_hard) { force_serial = 1; st.hard[L[limit].hardcls]++; }
+            else if (limit < nlive && ncom == 0 && !(opos + 1 < ZO_SUBBLOCK_SYMS)) { /* sub-block full */ }
+            if (ncom == 0 && !limit_is_hard && opos + 1 < ZO_SUBBLOCK_SYMS) { fprintf(stderr, "no progress at %d\n", P); return -1; }
+        }
+        cuts[4 * nsub] = tok_begin; cuts[4 * nsub + 1] = nt; cuts[4 * nsub + 2] = q; cuts[4 * nsub + 3] = opos;
+        nsub++;
+    }
+    st.tokens += nt;
+    *ncut = nsub;
+    return nt;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s FILE [NL] [level] [fix] [max_bytes]\n", argv[0]); return 2; }
+    const int NL = argc > 2 ? atoi(argv[2]) : 256, level = argc > 3 ? atoi(argv[3]) : 0, fix = argc > 4 ? atoi(argv[4]) : 1;
+    const long maxb = argc > 5 ? atol(argv[5]) : (1L << 62);
+    if (argc > 6) precise_risk = atoi(argv[6]);
+    FILE* f = fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 2; }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    if (n > maxb) n = maxb;
+    uint8_t* x = (uint8_t*)malloc((size_t)n + 1024); memset(x + n, 0, 1024);
+    if (fread(x, 1, (size_t)n, f) != (size_t)n) return 2;
+    fclose(f);
+    tables_init();
+    zo_stream* sm = zo_stream_new(level); zo_stream* so = zo_stream_new(level);
+    uint32_t* tm = (uint32_t*)malloc(sizeof(uint32_t) * (ZO_BLOCK_IN + 64));
+    uint32_t* to = (uint32_t*)malloc(sizeof(uint32_t) * ZO_SUBBLOCK_SYMS);
+    static int cuts[4 * 200];
+    int bad = 0;
+    for (long off = 0; off < n && !bad; off += ZO_BLOCK_IN) {
+        const int ilen = (int)(n - off < ZO_BLOCK_IN ? n - off : ZO_BLOCK_IN);
+        int ncut = 0;
+        const int nt = parse_block_model(sm, x + off, ilen, level, NL, fix, tm, cuts, &ncut);
+        if (nt < 0) { bad = 1; break; }
+        zo_reset_buckets(so);
+        int enc = 0, sub = 0, at = 0;
+        while (enc < ilen) {
+            int rlen = 0;
+            const int k = zo_parse_subblock(so, level, x + off, ilen, &enc, to, &rlen, 0);
+            if (sub >= ncut || cuts[4 * sub + 1] - cuts[4 * sub] != k || cuts[4 * sub + 2] != enc || cuts[4 * sub + 3] != rlen) {
+                fprintf(stderr, "block at %ld sub %d: cut mismatch (model %d tokens enc %d rlen %d, oracle %d %d %d)\n", off, sub,
+                        sub < ncut ? cuts[4 * sub + 1] - cuts[4 * sub] : -1, sub < ncut ? cuts[4 * sub + 2] : -1, sub < ncut ? cuts[4 * sub + 3] : -1, k, enc, rlen);
+                bad = 1;
+            }
+            for (int i = 0; i < k && !bad; i++) if (tm[at + i] != to[i]) {
+                fprintf(stderr, "block at %ld sub %d token %d: model %08x oracle %08x\n", off, sub, i, tm[at + i], to[i]); bad = 1;
+            }
+            if (bad) break;
+            at += k; sub++;
+        }
+        if (!bad && (sub != ncut || at != nt)) { fprintf(stderr, "count mismatch\n"); bad = 1; }
+    }
+    printf("%s NL=%d level=%d fix=%d bytes=%ld: %s | rounds %ld tokens %ld committed/round %.1f positions/round %.1f iterations/round %.2f (max %ld) serial tokens/round %.3f "
+           "(key %ld ring %ld lazy %ld) fixes %ld lazyfixes %ld\n", argv[1], NL, level, fix, n, bad ? "MISMATCH" : "exact",
+           st.rounds, st.tokens, (double)st.committed / (st.rounds ? st.rounds : 1), (double)n / (st.rounds ? st.rounds : 1), (double)st.iters / (st.rounds ? st.rounds : 1), st.maxit,
+           (double)st.serial / (st.rounds ? st.rounds : 1), st.hard[1], st.hard[2], st.hard[3], st.fixes, st.lfixes);
+    printf("   iterations histogram:"); for (int i = 0; i < 16; i++) printf(" %ld", st.hist_it[i]); printf("\n");
+    return bad;
+}
