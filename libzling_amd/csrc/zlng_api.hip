@@ -103,7 +103,8 @@ struct zlng_ctx {
     uint32_t pending_blocks = 0;
 
     StageTimer timer;
-    int parser_kind = 2;              // 2 = single-wavefront speculative parser (default), 1 = serial cross-check form (ZLNG_PARSER=serial),
+    int parser_kind = 3;              // 3 = workgroup-wide window parser (rolz_wg.hip; default), 2 = the one-wavefront speculative parser of
+                                      // rounds 1-2 (ZLNG_PARSER=wave), 1 = serial cross-check form (ZLNG_PARSER=serial),
                                       // 0 = pipelined evaluator + resolver wavefronts (ZLNG_PARSER=pipe; exact, measured slower -- DESIGN.md)
 };
 
@@ -201,9 +202,11 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     static const int lazy_fix = getenv("ZLNG_LAZY_FIX") ? atoi(getenv("ZLNG_LAZY_FIX")) : 1;
     ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
                  c->tok_cap, blk0, overflow_flag(c), settle_pf, lazy_fix};
-    launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, c->parser_kind == 2 && c->level == 0);
+    static const int wg_waves = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
+    launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, c->parser_kind >= 2 && c->level == 0);
     timer_mark(c, "dict_reset");
-    if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
+    if (c->parser_kind == 3) launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves);
+    else if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
     else if (c->parser_kind == 0) { pa.pf_ahead = pipe_lead; pa.pf_waves = pipe_pf; launch_rolz_parse_pipe(pa, nb, c->stream, c->level == 0); }
     else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
     timer_mark(c, "rolz_parse");
@@ -479,7 +482,7 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     c->is_encode = is_encode != 0;
     c->max_blocks = (uint32_t)max_blocks;
     const char* pk = getenv("ZLNG_PARSER");
-    c->parser_kind = !pk ? 2 : (strcmp(pk, "serial") == 0 ? 1 : (strcmp(pk, "pipe") == 0 ? 0 : 2));
+    c->parser_kind = !pk ? 3 : (strcmp(pk, "serial") == 0 ? 1 : (strcmp(pk, "pipe") == 0 ? 0 : (strcmp(pk, "wave") == 0 ? 2 : 3)));
     int rc = ZLNG_OK;
     auto fail = [&](int code) { *err = code; zlng_destroy(c); return (zlng_ctx*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return fail(ZLNG_E_DEVICE);

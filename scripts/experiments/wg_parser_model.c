@@ -54,7 +54,7 @@ static struct {
     long hist_it[16];
 } st;
 
-static int precise_risk = 1;
+static int precise_risk = 1, only_s = 0, max_tok = 1 << 30;
 static int ring_dist(int node, int head0) { return (node - head0 - 1) & (ZO_RING - 1); }
 
 /* Read-only evaluation of `pos` as a token start against the dictionary as it is now (phase 1). */
@@ -211,10 +211,10 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 l->mnode_slot = l->sp_node; l->link_lane = -1;
             }
             /* ---- iterate to the fixed point */
-            int limit = nlive, limit_is_hard = 0, it = 0;
+            int limit = nlive, limit_is_hard = 0, it = 0, tok_limit = nlive;
             for (;; it++) {
                 memset(S, 0, (size_t)nlive + 1);
-                for (int g = 0; g < nlive; g += L[g].tlen) S[g] = 1;
+                { int cntS = 0, g = 0; for (; g < nlive && cntS < max_tok; g += L[g].tlen) { S[g] = 1; cntS++; } tok_limit = g < nlive ? g : nlive; }
                 /* E step A: previous token type, events */
                 int prev = -1;
                 for (int g = 0; g < nlive; g++) {
@@ -241,6 +241,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                         if (L[j].key == l->key) { if (a1 < 0) a1 = j; else if (a2 < 0) a2 = j; }
                     }
                     l->hard = 0; l->hardcls = 0;
+                    if (only_s && !S[g]) { l->ty2 = l->ty; l->tlen2 = l->tlen; l->mlen2 = l->mlen; l->mnode2 = l->mnode_slot; l->link2 = l->link_lane; continue; }
                     int is_match = 0, mlen = 3, mnode = 0, link = -1;
                     if (l->canm) {
                         const int ring = l->dmin <= k;
@@ -317,7 +318,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                     l->ty2 = ty; l->tlen2 = ty == TY_LIT ? 1 : 2;
                 }
                 /* cut of the round: first hard lane of S, or the sub-block's end */
-                limit = nlive; limit_is_hard = 0;
+                limit = tok_limit; limit_is_hard = 0;
                 { int sym = 0;
                   for (int g = 0; g < nlive; g++) if (S[g]) {
                       if (!(opos + sym + 1 < ZO_SUBBLOCK_SYMS)) { limit = g; break; }
@@ -387,6 +388,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
             if (limit_is_hard) { force_serial = 1; st.hard[L[limit].hardcls]++; }
             else if (limit < nlive && ncom == 0 && !(opos + 1 < ZO_SUBBLOCK_SYMS)) { /* sub-block full */ }
             if (ncom == 0 && !limit_is_hard && opos + 1 < ZO_SUBBLOCK_SYMS) { fprintf(stderr, "no progress at %d\n", P); return -1; }
+            (void)tok_limit;
         }
         cuts[4 * nsub] = tok_begin; cuts[4 * nsub + 1] = nt; cuts[4 * nsub + 2] = q; cuts[4 * nsub + 3] = opos;
         nsub++;
@@ -401,6 +403,8 @@ int main(int argc, char** argv) {
     const int NL = argc > 2 ? atoi(argv[2]) : 256, level = argc > 3 ? atoi(argv[3]) : 0, fix = argc > 4 ? atoi(argv[4]) : 1;
     const long maxb = argc > 5 ? atol(argv[5]) : (1L << 62);
     if (argc > 6) precise_risk = atoi(argv[6]);
+    if (argc > 7) only_s = atoi(argv[7]);
+    if (argc > 8) max_tok = atoi(argv[8]);
     FILE* f = fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 2; }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     if (n > maxb) n = maxb;

@@ -36,18 +36,33 @@ for it in range(2):
     print("iter %d: %d -> %d bytes, %.1f ms, %.1f MB/s" % (it, n, m, dt * 1e3, n / dt / 1e6))
     for name, ms in s.timings():
         print("   %-14s %10.3f ms" % (name, ms))
+if check:
+    z = dout[:m].cpu().numpy()
+    ref = Oracle().encode(x, level)
+    print("bit-exact vs oracle:", np.array_equal(z, ref))
+    check = False
 if os.environ.get("ZLNG_PROFILE") == "1":
     import ctypes as C
     SL = 24
     buf = (C.c_ulonglong * (SL * nb))()
     zl.lib().zlng_debug_counters(C.c_void_p(s._h), buf, nb)
-    if "--all" in sys.argv:
+    if "--all" in sys.argv and os.environ.get("ZLNG_PARSER") == "wave":
         for b in range(nb):
             d = buf[SL * b: SL * b + 24]
             r = max(d[3], 1)
             print("blk %2d: %5.0f Mcyc  rounds %6d tokens %7d  per round p1 %5.0f mask %5.0f p2 %5.0f  settled tails %.2f/round  problem tokens %.2f/round (conflicts %.2f, lazy fixes %.2f)  segments %.2f/round | p2 parts: chase+settle %4.0f validate %4.0f commit %4.0f serial %4.0f | per settled tail %4.0f cyc (%4.0f until the loads land)" % (
                 b, (d[0] + d[1] + d[2]) / 1e6, d[3], d[4], d[0] / r, d[1] / r, d[2] / r, d[17] / r, (d[6] + d[7]) / r, d[6] / r, d[20] / r, d[5] / r,
                 d[9] / r, d[15] / r, d[16] / r, d[8] / r, d[18] / max(d[17], 1), d[19] / max(d[17], 1)))
+    if os.environ.get("ZLNG_PARSER", "wg") == "wg":
+        for b in range(min(nb, 4) if "--all" not in sys.argv else nb):
+            d = buf[SL * b: SL * b + 24]
+            r = max(d[3], 1)
+            print("blk %2d wg: %5.0f Mcyc  rounds %6d tokens %7d  positions/round %.1f iterations/round %.2f serial tokens/round %.3f cut rounds %d | cycles per round: phase1 %5.0f tables %5.0f iterate %5.0f commit %5.0f | per serial token %5.0f" % (
+                b, (d[0] + d[1] + d[2] + d[9] + d[8]) / 1e6, d[3], d[4], d[7] / r, d[5] / r, d[6] / r, d[11], d[0] / r, d[1] / r, d[2] / r, d[9] / r, d[8] / max(d[6], 1)))
+            i = max(d[5], 1)
+            print("        per iteration: closure+chase %5.0f  A(+B2) %5.0f  B(+B3) %5.0f  C match/fix %5.0f  C lazy %5.0f  C mru %5.0f  B4+limit %5.0f | tables: closure+B1 %5.0f per round" % (
+                d[12] / i, d[13] / i, d[14] / i, d[15] / i, d[16] / i, d[17] / i, d[18] / i, d[19] / r))
+        sys.exit(0)
     for b in range(min(nb, 4)):
         d = buf[SL * b: SL * b + 8]
         e = buf[SL * b + 8: SL * b + 24]
