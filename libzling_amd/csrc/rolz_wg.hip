@@ -11,12 +11,12 @@
 //
 //   phase 1   every lane evaluates its position AS IF it were a token start against the dictionary as of the start of the
 //             round (read only): hash head, chain nodes, longest match, lazy probes (rolz_dev.h speculation).
-//   tables    lane-mask tables in LDS give every lane the lanes of the window that share its hash slot (ctx, hash13), its
-//             bucket, its lazy probes' slots and buckets, and its word-MRU keys (hashed tables are verified against the
-//             exact keys, so the masks are exact).
+//   tables    every (ctx, hash13) of the window gets a row of an LDS table of its own (open addressing, exact); buckets and
+//             word-MRU keys index their tables directly.
 //   iterate   S = the token starts reached from lane 0 under the current per-lane token lengths (pointer doubling inside a
-//             wavefront, one hop per wavefront across them).  Then E(g, S): every lane re-evaluates its own token GIVEN the
-//             accepted starts before it --
+//             wavefront, one hop per wavefront across them), at most 64 per round, numbered by RANK.  The tokens of S put their
+//             rank bit into the rows of their hash slot, bucket and MRU key, so that every relation a token needs is ONE 64-bit
+//             mask.  Then E(g, S): every token of S re-evaluates itself GIVEN the tokens before it --
 //               * the word MRU of its context after every boundary event of S up to g (src/libzling_lz.cpp:163-191: which
 //                 boundaries push, conditionally or not, follows from the token types of S; the two slots follow from the
 //                 last event and the last EFFECTIVE event of the key: all mask arithmetic);
@@ -43,9 +43,8 @@ namespace zlng {
 
 typedef unsigned long long u64;
 
-constexpr int kWgKeyTab = 2048;                     // rows of the hashed (ctx, hash13) lane-mask table
 
-__device__ __forceinline__ uint32_t wg_key_ix(uint32_t key21) { return ((key21 & 0x1FFFu) ^ ((key21 >> 13) * 0x9E5u) ^ (key21 >> 7)) & (kWgKeyTab - 1); }
+__device__ __forceinline__ uint32_t wg_key_ix(uint32_t key21) { return ((key21 & 0x1FFFu) ^ ((key21 >> 13) * 0x9E5u) ^ (key21 >> 7)) & 2047u; }
 __device__ __forceinline__ u64 uni64(u64 v) { return (u64)ufl((uint32_t)(v >> 32)) << 32 | ufl((uint32_t)v); }
 
 // What phase 1 leaves for one lane.
@@ -65,7 +64,7 @@ struct WSpec {
 // trips after the window's text with the wide slot plane (rolz_dev.h speculate_l0w explains the link copy), then -- only if some
 // lane's compare ran to 16 bytes -- the tails (32 bytes per trip, both nodes in one loop) and the lazy probes of those lanes.
 template <bool kWide>
-__device__ __forceinline__ void speculate_l0t(WSpec& W, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t pos,
+__device__ __forceinline__ void speculate_l0t(WSpec& W, Quad& ql_out, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t pos,
                                               const Quad qa, uint32_t t16, uint32_t ctx, uint32_t hc, uint32_t chk) {
     const uint32_t w4 = qa.a;
     const uint32_t lctx1 = w4 & 0xFF;
@@ -144,6 +143,15 @@ __device__ __forceinline__ void speculate_l0t(WSpec& W, uint8_t* dict, const uin
     W.lkey1 = lctx1 << 13 | hh1; W.lkey2 = 0;
     W.ld1 = hasl ? ring_dist(ln1, lhead1) : (uint32_t)kRing - 1u; W.ld2 = kRing - 1;
     W.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u);
+    ql_out = ql;                                      // first 16 source bytes of the probe's chain head (a changed length re-probes from them)
+}
+
+// The 4 bytes at byte offset `off` (0..13, or ..16 with `next` = the dword behind the quad) of a 16-byte group.
+__device__ __forceinline__ uint32_t byte_window(const Quad q, uint32_t next, uint32_t off) {
+    const uint32_t dw = off >> 2;
+    const uint32_t lo = dw == 0u ? q.a : dw == 1u ? q.b : dw == 2u ? q.c : dw == 3u ? q.d : next;
+    const uint32_t hi = dw == 0u ? q.b : dw == 1u ? q.c : dw == 2u ? q.d : next;
+    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
 }
 
 // GetCommonLength (src/libzling_lz.cpp:66-89) of the lane's position (first 16 bytes in qa) with another position of the block.
@@ -155,100 +163,51 @@ __device__ __forceinline__ uint32_t lcp_with(const uint8_t* buf, uint32_t pos, u
     return len;
 }
 
-// ---- NW-word lane masks: M per lane (VGPRs), U wave-uniform (SGPRs).  `wv` = this wavefront, `own` = which lanes of its
-// own word count (below / below-or-equal the lane); words of later wavefronts never count.
-template <int NW>
-__device__ __forceinline__ int top_in(const u64* M, const u64* U, int wv, u64 own) {
-    int r = -1;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        if (w <= wv) {
-            u64 m = M[w] & U[w];
-            if (w == wv) m &= own;
-            if (m) r = 64 * w + top_bit(m);
-        }
+constexpr int kWgRows = 2048;                       // rows of the exact (ctx, hash13) table (open addressing over the keys of one round)
+constexpr uint32_t kWgEmpty = 0xFFFFFFFFu;
+
+// The two MRU slots of a key after the boundary events whose token ranks are in M (newest = highest rank), given the key's slots
+// m0 at the start of the round (src/libzling_lz.cpp:163-166, 181-182, 190-191).  Slot 0 is the word of the newest event: a
+// conditional push leaves it that word whether it pushes or not.  Slot 1 is what slot 0 was just before the newest EFFECTIVE
+// event (unconditional, or conditional with a word that differs from slot 0 at that moment).  t_ev[r] = word of token r's event,
+// COND = tokens whose event is conditional (it follows a match).  false: not settled within `bound` events (the lane goes hard).
+__device__ __forceinline__ bool ev_state(u64 M, u64 COND, uint32_t m0, const uint32_t* t_ev, uint32_t& s0, uint32_t& s1, int bound) {
+    s0 = m0 & 0xFFFF; s1 = m0 >> 16;
+    if (M == 0ull) return true;
+    int e = top_bit(M);
+    uint32_t w = t_ev[e] & 0xFFFF;
+    s0 = w;
+    u64 cur = M & ~(1ull << e);
+    for (int i = 0; i < bound; i++) {
+        const uint32_t pw = cur ? (t_ev[top_bit(cur)] & 0xFFFF) : (m0 & 0xFFFF);
+        const bool eff = !((COND >> e) & 1ull) || w != pw;
+        if (eff) { s1 = pw; return true; }
+        if (!cur) return true;                       // no effective event in the round: slot 1 as it was
+        e = top_bit(cur); cur &= ~(1ull << e); w = pw;
     }
-    return r;
-}
-template <int NW>
-__device__ __forceinline__ uint32_t cnt_in(const u64* M, const u64* U, int wv, u64 own) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        if (w <= wv) {
-            u64 m = M[w] & U[w];
-            if (w == wv) m &= own;
-            c += (uint32_t)__popcll(m);
-        }
-    }
-    return c;
-}
-// count of (M & U) strictly below the global lane `b` (per-lane b)
-template <int NW>
-__device__ __forceinline__ uint32_t cnt_below_lane(const u64* M, const u64* U, int b) {
-    uint32_t c = 0;
-    const int bw = b >> 6;
-    const u64 bm = (1ull << (b & 63)) - 1ull;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        u64 m = M[w] & U[w];
-        m = w < bw ? m : (w == bw ? (m & bm) : 0ull);
-        c += (uint32_t)__popcll(m);
-    }
-    return c;
-}
-template <int NW>
-__device__ __forceinline__ bool any_above(const u64* M, const u64* U, int wv, u64 above_own) {      // lanes after this one
-    bool r = false;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        if (w >= wv) {
-            u64 m = M[w] & U[w];
-            if (w == wv) m &= above_own;
-            r = r || m != 0ull;
-        }
-    }
-    return r;
+    return false;
 }
 
-// Keep of a hashed mask row only the lanes whose exact key is `want` (lanes of this wavefront's word limited to `own`, later
-// wavefronts dropped).  Candidates are rare (the table has 8 rows per lane), so the loop usually does not run at all.
-template <int NW>
-__device__ __forceinline__ void verify_row(u64* M, const uint32_t* a_key, uint32_t want, int wv, u64 own, bool act) {
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        if (w > wv) { M[w] = 0ull; continue; }
-        u64 c = act ? M[w] : 0ull;
-        if (w == wv) c &= own;
-        u64 keep = 0ull;
-        while (__any(c != 0ull)) {
-            if (c != 0ull) {
-                const int b = (int)__builtin_ctzll(c);
-                if ((a_key[64 * w + b] & 0x1FFFFFu) == want) keep |= 1ull << b;
-                c &= c - 1ull;
-            }
-        }
-        M[w] = keep;
-    }
-}
-
+// One workgroup per block.  NW wavefronts; lane g = 64 * wavefront + lane stands for position P + g.  The fixed-point iteration
+// works on the TOKENS of S, numbered by rank (their order in S; at most 64 per round): every relation between tokens -- same hash
+// slot, same bucket, same MRU key -- is one 64-bit rank mask in LDS, rebuilt per iteration by the tokens of S themselves.
 template <int NW, bool kAllL0, bool kProf>
 __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     constexpr int NL = 64 * NW;
     __shared__ uint16_t heads[256];
     __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
-    // lane-mask tables, NW words per row; the extra last row of each is a sink for lanes that must not deposit
-    __shared__ u64 keytab[(kWgKeyTab + 1) * NW];
-    __shared__ u64 ctxtab[257 * NW];
-    __shared__ u64 ektab[257 * NW];
-    __shared__ uint32_t a_key[NL];                   // per lane: key21 | chk << 21
-    __shared__ uint32_t a_ev[NL];                    // per lane: event word | event key << 16
-    __shared__ uint32_t a_st[NL];                    // per lane: token kind | token length << 8
-    __shared__ uint32_t a_s0b[NL];                   // per lane: MRU slot 0 of its event key just before its event
-    __shared__ uint32_t a_succ[NL];                  // per lane: lowest lane of S that links to it in its hash slot (NL = none)
+    __shared__ uint32_t ht_key[kWgRows];             // exact key of a row of keyrow (open addressing; kWgEmpty = free)
+    __shared__ u64 keyrow[2][kWgRows + 1];           // tokens of S per (ctx, hash13); two buffers alternate between iterations;
+    __shared__ u64 ctxrow[2][257];                   // tokens of S per bucket                  the extra last row is a sink
+    __shared__ u64 ekrow[2][257];                    // tokens of S per MRU event key
+    __shared__ uint32_t a_st[NL];                    // per lane: token kind | token length << 8 (what the chain was built from)
     __shared__ uint32_t c_exit[NL];                  // closure: first chain position beyond the lane's wavefront (global lane index)
     __shared__ u64 c_mask[NL];                       // closure: chain positions inside the lane's wavefront
-    __shared__ u64 u_ev[NW], u_eff[NW], u_hard[NW], u_chg[NW], u_mat[NW], u_cut[NW];
+    __shared__ uint32_t t_lane[64], t_ev[64], t_key[64];   // per token of S: its lane, event word | key << 16, key21 | chk << 21
+    __shared__ Quad t_q[64];                         // per token of S: the 16 bytes at its position
+    __shared__ uint32_t t_flag[64];                  // per token of S: has an event | conditional << 1
+    __shared__ uint32_t t_res[64];                   // per token of S, after E: hard << 2 | changed << 3 | match << 4
+    __shared__ u64 u_cut;
     __shared__ uint32_t u_ser[4];                    // serial token: q, opos, nt, kind
 
     const uint32_t blk = blockIdx.x + a.blk0;
@@ -263,25 +222,27 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     const int lane = tid & 63;
     const int wv = (int)ufl((uint32_t)(tid >> 6));
     const u64 lane_bit = 1ull << lane;
-    const u64 below = lane_bit - 1ull, beloweq = below | lane_bit, above = ~beloweq;
+    const u64 lbelow = lane_bit - 1ull;
     constexpr bool kWide = kAllL0;                   // slot plane form (zlng_common.h): the launcher's reset matches
 
-    for (int i = tid; i < 257 * NW; i += NL) { ctxtab[i] = 0; ektab[i] = 0; }
-    for (int i = tid; i < (kWgKeyTab + 1) * NW; i += NL) keytab[i] = 0;
+    for (int i = tid; i < 2 * 257; i += NL) { (&ctxrow[0][0])[i] = 0; (&ekrow[0][0])[i] = 0; }
+    for (int i = tid; i < 2 * (kWgRows + 1); i += NL) (&keyrow[0][0])[i] = 0;
+    for (int i = tid; i < kWgRows; i += NL) ht_key[i] = kWgEmpty;
     for (int i = tid; i < 256; i += NL) heads[i] = 0;
     __syncthreads();
 
     uint32_t nt = 0;
     int q = 0, nsub = 0;
     bool overflow = false;
-    u64 c_p1 = 0, c_tab = 0, c_it = 0, c_com = 0, c_ser = 0, n_round = 0, n_iter = 0, n_ser = 0, n_hard[4] = {0, 0, 0, 0}, n_pos = 0, n_cutr = 0;
-    u64 c_a = 0, c_b = 0, c_c1 = 0, c_c2 = 0, c_c3 = 0, c_lim = 0, c_cl = 0, c_t1 = 0, c_t2 = 0;
+    u64 c_p1 = 0, c_tab = 0, c_it = 0, c_com = 0, c_ser = 0, n_round = 0, n_iter = 0, n_ser = 0, n_hardr = 0, n_pos = 0, n_cutr = 0;
+    u64 c_dep = 0, c_ev = 0, c_lim = 0, c_x1 = 0, c_x2 = 0, c_x3 = 0;
     const bool prof = kProf && a.dbg != nullptr;
 
     while (q < ilen && !overflow) {                  // ---- one sub-block (one EncodeImpl call)
         const uint32_t lvl = kAllL0 ? 0u : (uint32_t)a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)];
         const LevelCfg cfg = level_cfg((int)lvl);
         const bool level0 = kAllL0 || lvl == 0u;
+        const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
         const uint32_t tok_begin = nt;
         int opos = 0;
         uint32_t prevty = kTyNone;                   // kind of the token that ended at q (none: the MRU starts empty)
@@ -296,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
 
         while (q < ilen && opos + 1 < kSubSyms) {
             q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
-            if (nt + (uint32_t)NL > a.tok_cap) { overflow = true; break; }
+            if (nt + 64u > a.tok_cap) { overflow = true; break; }
 
             if (serial_next) {
                 // ---------------- exact serial token at q (a hard lane): the pending boundary event, then MatchAndUpdate /
@@ -365,9 +326,10 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
             const uint32_t ek = b_m3, ew = b_m2 << 8 | ctx;        // event at this boundary: mru[b-3] <- (b-2, b-1)
 
             WSpec W;
-            uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
+            const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
+            Quad ql = {0, 0, 0, 0};
             if (level0) {
-                speculate_l0t<kWide>(W, dict, buf, heads[ctx], heads[lctx1], upos, qtext, t16, ctx, hc, chk);
+                speculate_l0t<kWide>(W, ql, dict, buf, heads[ctx], heads[lctx1], upos, qtext, t16, ctx, hc, chk);
             } else {
                 Spec S1;
                 S1.sp = kMatchMin - 1; S1.node0 = 65535; S1.head0 = 0; S1.dmin = kRing - 1;
@@ -382,27 +344,29 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 W.ld1 = S1.ld1; W.ld2 = S1.ld2; W.lsrc1 = 0;
             }
             const uint32_t head0 = heads[ctx];
-            const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
+            const uint32_t m0c = mru[ctx], m0e = mru[ek];           // MRU slots of my check key / my event key at the start of the round
             // speculative token of this lane
             const bool sp_veto = (want1 && W.veto1) || (want2 && W.veto2);
             const bool sp_match = canm && W.len >= (uint32_t)kMatchMin && !(W.len < (uint32_t)kLazyLimit && sp_veto);
             uint32_t ty = sp_match ? kTyMatch : kTyLit;            // token kind / length / match of this lane under the current S
             uint32_t tlen = sp_match ? W.len : 1u;
-            uint32_t mlen = W.len, mnode = W.node;                  // mnode: ring slot, or 0x10000 | lane for a start of this round
-            int link = -1;                                          // in-slot predecessor among the starts of this round (-1: the snapshot's head)
-            uint32_t link_chk = 0;
-            uint32_t k_ctx = 0;                                     // accepted earlier starts in my bucket
+            uint32_t mlen = W.len, mnode = W.node;                  // mnode: ring slot, or 0x10000 | rank for a token of this round
+            int link = -1;                                          // rank of my in-slot predecessor among the tokens of this round (-1: the snapshot's head)
+            uint32_t link_chk = 0, link_lane = 0;
             if (prof) t1 = __builtin_readcyclecounter();
 
-            // ---------------- tables and per-lane arrays
-            const uint32_t kix = canm ? wg_key_ix(key) : (uint32_t)kWgKeyTab, ctx_w = canm ? ctx : 256u, ek_w = live ? ek : 256u;
-            atomicOr(&keytab[kix * NW + wv], lane_bit);
-            atomicOr(&ctxtab[ctx_w * NW + wv], lane_bit);
-            atomicOr(&ektab[ek_w * NW + wv], lane_bit);
-            a_key[tid] = key | chk << 21;
-            a_ev[tid] = ew | ek << 16;
+            // ---------------- exact table rows of the round's keys (open addressing: a row belongs to ONE key)
+            uint32_t r_key = kWgRows;
+            if (canm) {
+                uint32_t slot = wg_key_ix(key);
+                while (true) {
+                    const uint32_t old = atomicCAS(&ht_key[slot], kWgEmpty, key);
+                    if (old == kWgEmpty || old == key) break;
+                    slot = (slot + 1u) & (kWgRows - 1);
+                }
+                r_key = slot;
+            }
             a_st[tid] = ty | tlen << 8;
-            a_succ[tid] = (uint32_t)NL;
 
             // closure of the token chain inside this wavefront: after the loop every lane knows the positions of its own
             // wavefront its chain passes (mask) and where the chain leaves the wavefront (nxg, a global lane index)
@@ -420,50 +384,45 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 }
                 c_exit[tid] = nxg; c_mask[tid] = mk;
             };
-            u64 tq1 = 0, tq2 = 0;
-            if (prof) tq1 = __builtin_readcyclecounter();
             closure();
-            __syncthreads();                                        // (B1) tables, arrays, closure are in LDS
-            if (prof) { tq2 = __builtin_readcyclecounter(); c_t1 += tq2 - tq1; }
-
-            // exact masks of this lane
-            u64 KM[NW], CM[NW], LK1[NW], LC1[NW], LK2[NW], LC2[NW], EKC[NW], EKS[NW];
-            {
-                const uint32_t lk1 = canm ? wg_key_ix(W.lkey1) : (uint32_t)kWgKeyTab, lc1 = canm ? lctx1 : 256u;
-                const uint32_t lk2 = (canm && want2) ? wg_key_ix(W.lkey2) : (uint32_t)kWgKeyTab, lc2 = (canm && want2) ? lctx2 : 256u;
-                const uint32_t ekc = live ? ctx : 256u;
-#pragma unroll
-                for (int w = 0; w < NW; w++) {
-                    KM[w] = keytab[kix * NW + w]; CM[w] = ctxtab[ctx_w * NW + w];
-                    LK1[w] = keytab[lk1 * NW + w]; LC1[w] = ctxtab[lc1 * NW + w];
-                    LK2[w] = keytab[lk2 * NW + w]; LC2[w] = ctxtab[lc2 * NW + w];
-                    EKC[w] = ektab[ekc * NW + w]; EKS[w] = ektab[ek_w * NW + w];
+            __syncthreads();                                        // (B1) rows claimed, a_st and the closure are in LDS
+            // rows of my lazy probes' keys (the sink row if no position of the window has that key)
+            auto find_row = [&](uint32_t k21, bool want) -> uint32_t {
+                uint32_t slot = wg_key_ix(k21), r = kWgRows;
+                bool go = want;
+                while (__any(go)) {
+                    if (go) {
+                        const uint32_t v = ht_key[slot];
+                        if (v == k21) { r = slot; go = false; }
+                        else if (v == kWgEmpty) go = false;
+                        else slot = (slot + 1u) & (kWgRows - 1);
+                    }
                 }
-                verify_row<NW>(KM, a_key, key, wv, below, canm);
-                verify_row<NW>(LK1, a_key, W.lkey1, wv, beloweq, canm);
-                if (want2) verify_row<NW>(LK2, a_key, W.lkey2, wv, beloweq, canm);
-                if (!canm) {
-#pragma unroll
-                    for (int w = 0; w < NW; w++) { CM[w] = 0; LC1[w] = 0; LC2[w] = 0; }
-                }
-                if (!live) {
-#pragma unroll
-                    for (int w = 0; w < NW; w++) { EKC[w] = 0; EKS[w] = 0; }
-                }
-            }
+                return r;
+            };
+            const uint32_t r_lk1 = find_row(W.lkey1, canm && want1);
+            const uint32_t r_lk2 = want2 ? find_row(W.lkey2, canm) : (uint32_t)kWgRows;
+            const uint32_t ctx_r = canm ? ctx : 256u, lc1_r = (canm && want1) ? lctx1 : 256u, lc2_r = (canm && want2) ? lctx2 : 256u;
+            const uint32_t ek_r = live ? ek : 256u, ekc_r = live ? ctx : 256u;
             if (prof) t2 = __builtin_readcyclecounter();
 
             // ---------------- iterate to the fixed point
-            u64 S[NW], EV[NW], EFF[NW], MAT[NW];
-            int limit = 0;
+            u64 KM = 0, CM = 0, EKS = 0, EVu = 0, CONDu = 0, MATu = 0;
+            uint32_t rank = 0, ntok = 0, k_ctx = 0;
+            bool inS = false, has_ev = false;
+            u64 rbit = 0, rbelow = 0;
+            int limit = 0;                                          // tokens (ranks) the round commits
             bool limit_hard = false;
-            bool has_ev = false, cond = false, eff = false;
-            uint32_t s0b = 0;
+            u64 dep_prev = 0;                                       // my bit in the previous iteration's row buffer (cleared one iteration later)
+            uint32_t dep_prev_rows = 0;
+            int itn = 0;
             for (int it = 0;; it++) {
-                u64 ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0, th = 0;
+                itn = it;
+                const int bufi = it & 1;
+                u64 ta = 0, tb = 0, tc = 0, td = 0;
                 if (prof) ta = __builtin_readcyclecounter();
-                if (it > 0) { closure(); __syncthreads(); }
                 // chase: one hop per wavefront (every wavefront walks it; the result is uniform)
+                u64 S[NW];
 #pragma unroll
                 for (int w = 0; w < NW; w++) S[w] = 0ull;
                 {
@@ -477,264 +436,271 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                         e = nxe;
                     }
                 }
-                const bool inS = ((S[wv] >> lane) & 1ull) != 0;
-                if (prof) tb = __builtin_readcyclecounter();
-                // E step A: kind of the previous token, boundary events (src/libzling_lz.cpp:163-166, 181-182, 190-191)
-                {
-                    u64 ones[NW];
+                u64 tx1 = 0, tx2 = 0;
+                if (prof) tx1 = __builtin_readcyclecounter();
+                // rank of my token in S (tokens beyond the 64th wait for the next round)
+                uint32_t pre = 0; ntok = 0;
+                u64 Sown = 0, Sprev = 0;
 #pragma unroll
-                    for (int w = 0; w < NW; w++) ones[w] = ~0ull;
-                    const int pl = top_in<NW>(ones, S, wv, below);
-                    const uint32_t pty = pl >= 0 ? (a_st[pl] & 0xFF) : prevty;
-                    has_ev = live && (pty == kTyMatch || pty == kTyLit || pty == kTyW1);
-                    cond = pty == kTyMatch;
-                    const u64 evb = __ballot(has_ev && inS);
-                    if (lane == 0) u_ev[wv] = evb;
+                for (int w = 0; w < NW; w++) {
+                    if (w < wv) pre += (uint32_t)__popcll(S[w]);
+                    if (w == wv) Sown = S[w];
+                    if (w + 1 == wv) Sprev = S[w];
+                    ntok += (uint32_t)__popcll(S[w]);
                 }
-                __syncthreads();                                    // (B2)
+                rank = pre + (uint32_t)__popcll(Sown & lbelow);
+                inS = ((Sown >> lane) & 1ull) != 0 && rank < 64u;
+                if (ntok > 64u) ntok = 64u;
+                rbit = inS ? 1ull << (rank & 63u) : 0ull;
+                rbelow = rbit - 1ull;                               // (only used when inS)
+                // kind of the previous token from my two neighbours (a literal ends one position back, a word two, anything else is a match)
+                {
+                    const u64 s1 = Sown << 1 | Sprev >> 63, s2 = Sown << 2 | Sprev >> 62;
+                    const uint32_t st1 = a_st[tid >= 1 ? tid - 1 : 0], st2 = a_st[tid >= 2 ? tid - 2 : 0];
+                    const bool in1 = tid >= 1 && ((s1 >> lane) & 1ull) != 0, in2 = tid >= 2 && ((s2 >> lane) & 1ull) != 0;
+                    const uint32_t ty1 = st1 & 0xFF, ty2_ = st2 & 0xFF;
+                    uint32_t pty = kTyMatch;
+                    if (in2 && (ty2_ == kTyW0 || ty2_ == kTyW1)) pty = ty2_;
+                    if (in1 && ty1 == kTyLit) pty = kTyLit;
+                    if (tid == 0) pty = prevty;
+                    has_ev = inS && (pty == kTyMatch || pty == kTyLit || pty == kTyW1);
+                    const bool cond = pty == kTyMatch;
+                    if (prof) tx2 = __builtin_readcyclecounter();
+                    // the tokens of S put themselves into the rows of this iteration's buffer
+                    if (inS) {
+                        if (canm) { atomicOr(&keyrow[bufi][r_key], rbit); atomicOr(&ctxrow[bufi][ctx_r], rbit); }   // (the sink rows stay empty)
+                        atomicOr(&ekrow[bufi][ek_r], rbit);
+                        t_flag[rank] = (has_ev ? 1u : 0u) | (cond ? 2u : 0u);
+                        t_lane[rank] = (uint32_t)tid; t_ev[rank] = ew | ek << 16; t_key[rank] = key | chk << 21; t_q[rank] = qtext;
+                    }
+                }
+                if (prof) { tb = __builtin_readcyclecounter(); c_x1 += tx1 - ta; c_x2 += tx2 - tx1; c_x3 += tb - tx2; }
+                __syncthreads();                                    // (Bb) rows and token arrays of this iteration are complete
+                if (it == 0 && canm) ht_key[r_key] = kWgEmpty;      // every lookup of the round is done
+                // my bits of the PREVIOUS iteration's buffer go now (nobody reads it any more, nobody writes it before the next barrier)
+                if (dep_prev) {
+                    atomicAnd(&keyrow[bufi ^ 1][dep_prev_rows & 0xFFFu], ~dep_prev);
+                    atomicAnd(&ctxrow[bufi ^ 1][(dep_prev_rows >> 12) & 0x1FFu], ~dep_prev);
+                    atomicAnd(&ekrow[bufi ^ 1][(dep_prev_rows >> 21) & 0x1FFu], ~dep_prev);
+                }
+                dep_prev = rbit; dep_prev_rows = r_key | ctx_r << 12 | ek_r << 21;
+                {   // uniform masks over the tokens: every wavefront reads the 64 flag words and votes (no same-address atomics)
+                    const uint32_t f = (uint32_t)lane < ntok ? t_flag[lane] : 0u;
+                    EVu = __ballot((f & 1u) != 0); CONDu = __ballot((f & 3u) == 3u);
+                }
                 if (prof) tc = __builtin_readcyclecounter();
-                if (it == 0) {                                      // every wavefront has read its rows: each lane clears what it set
-                    keytab[kix * NW + wv] = 0; ctxtab[ctx_w * NW + wv] = 0; ektab[ek_w * NW + wv] = 0;
-                }
-#pragma unroll
-                for (int w = 0; w < NW; w++) EV[w] = uni64(u_ev[w]);
-                // E step B: slot 0 of my event key just before my event; is my push effective?
-                {
-                    const int e = top_in<NW>(EKS, EV, wv, below);
-                    const uint32_t m0e = mru[ek_w & 255u];
-                    s0b = e >= 0 ? (a_ev[e] & 0xFFFF) : (m0e & 0xFFFF);
-                    eff = has_ev && (!cond || ew != s0b);
-                    a_s0b[tid] = s0b;
-                    const u64 efb = __ballot(eff && inS);
-                    if (lane == 0) u_eff[wv] = efb;
-                }
-                __syncthreads();                                    // (B3)
-                if (prof) td = __builtin_readcyclecounter();
-#pragma unroll
-                for (int w = 0; w < NW; w++) EFF[w] = uni64(u_eff[w]);
-                // E step C: my match given the accepted starts before me
-                bool hard = false;
-                uint32_t hcls = 0; (void)hcls;
-                bool is_match = false;
+
+                // ---- E: my token given the tokens of S before me.  Straight-line: every lane computes, the tokens of S keep the result
+                // (divergent branches cost a lone wavefront more than the selects do); only rare work sits behind uniform branches.
+                KM = keyrow[bufi][r_key]; CM = ctxrow[bufi][ctx_r]; EKS = ekrow[bufi][ek_r];
+                const u64 LK1 = keyrow[bufi][r_lk1], LC1 = ctxrow[bufi][lc1_r], EKC = ekrow[bufi][ekc_r];
+                const u64 rbeq = rbelow | rbit;
+                const uint32_t k = (uint32_t)__popcll(CM & rbelow);
+                k_ctx = k;
+                bool hard, is_match;
                 uint32_t ml = kMatchMin - 1, mn = 0;
                 int lk = -1;
-                uint32_t lkchk = 0;
-                const uint32_t k = cnt_in<NW>(CM, S, wv, below);
-                k_ctx = k;
+                uint32_t lkchk = 0, lklane = 0;
+                const bool ecan = inS && canm;
                 if (level0) {
-                    int a1 = top_in<NW>(KM, S, wv, below), a2 = -1;
-                    if (__any(a1 >= 0)) {
-                        u64 K2[NW];
-#pragma unroll
-                        for (int w = 0; w < NW; w++) K2[w] = (a1 >= 0 && (a1 >> 6) == w) ? (KM[w] & ~(1ull << (a1 & 63))) : KM[w];
-                        a2 = a1 >= 0 ? top_in<NW>(K2, S, wv, below) : -1;
-                    }
+                    const u64 kq = KM & rbelow;
+                    const bool has_a1 = kq != 0ull;
+                    const int a1 = top_bit(kq | 1ull);
+                    const u64 kq2 = kq & ~(1ull << a1);
+                    const bool has_a2 = has_a1 && kq2 != 0ull;
+                    const int a2 = has_a2 ? top_bit(kq2 | 1ull) : a1;
                     const bool ring0 = W.has0 && W.d0 <= k, ring1 = W.has1 && W.d1 <= k;
-                    if (canm) {
-                        if (a1 >= 0 ? (a2 < 0 && ring0) : ring0) { hard = true; hcls = 2; }
-                        else if (a1 < 0 && ring1) {
-                            // node 1's slot was rewritten by a start of this round: it holds a later position than node 0's now, so
-                            // the reference's chain-end test (src/libzling_lz.cpp:265) stops the walk behind node 0
-                            ml = W.len0 > 3u ? W.len0 : 3u; mn = W.node0; is_match = ml >= (uint32_t)kMatchMin;
-                        } else if (a1 < 0) { is_match = W.len >= (uint32_t)kMatchMin; ml = W.len; mn = W.node; }
-                    }
-                    const bool fixl = canm && !hard && a1 >= 0;
+                    hard = ecan && (has_a1 ? (!has_a2 && ring0) : ring0);
+                    // no token of this round in my hash slot: the speculation stands -- unless node 1's slot was rewritten by one (ring1): it
+                    // holds a later position than node 0's now, and the reference's chain-end test (src/libzling_lz.cpp:265) stops the walk there
+                    ml = ring1 ? (W.len0 > 3u ? W.len0 : 3u) : W.len;
+                    mn = ring1 ? W.node0 : W.node;
+                    const bool fixl = ecan && !hard && has_a1;
                     if (__any(fixl)) {
                         // the chain is [a1, a2 | the snapshot's head] (depth 2): candidate lengths from the window's own text
-                        const uint32_t k1 = a_key[fixl ? a1 : tid], k2 = a_key[(fixl && a2 >= 0) ? a2 : tid];
-                        const bool c1 = fixl && (k1 >> 21) == chk, c2 = fixl && a2 >= 0 && (k2 >> 21) == chk;
-                        const uint32_t l1 = lcp_with(buf, upos, (uint32_t)(P + (c1 ? a1 : 0)), qtext, c1);
-                        uint32_t l2 = 0;
-                        if (__any(c2)) l2 = lcp_with(buf, upos, (uint32_t)(P + (c2 ? a2 : 0)), qtext, c2);
-                        if (fixl) {
-                            const bool second = a2 >= 0 || W.has0;
-                            const uint32_t ls = a2 >= 0 ? l2 : W.len0, ns = a2 >= 0 ? (0x10000u | (uint32_t)a2) : W.node0;
-                            ml = kMatchMin - 1; mn = 0;
-                            if (l1 > ml) { ml = l1; mn = 0x10000u | (uint32_t)a1; }
-                            if (ml != (uint32_t)kMatchMax && second && ls > ml) { ml = ls; mn = ns; }
-                            is_match = ml >= (uint32_t)kMatchMin;
-                            lk = a1; lkchk = k1 >> 21;
+                        const uint32_t k1 = t_key[a1], k2 = t_key[a2], la1 = t_lane[a1], la2 = t_lane[a2];
+                        const Quad q1 = t_q[a1], q2 = t_q[a2];
+                        const bool c1 = fixl && (k1 >> 21) == chk, c2 = fixl && has_a2 && (k2 >> 21) == chk;
+                        uint32_t l1 = c1 ? lcp16(qtext, q1) : 0u, l2 = c2 ? lcp16(qtext, q2) : 0u;
+                        const bool g1 = c1 && l1 == 16u, g2 = c2 && l2 == 16u;
+                        if (__any(g1 || g2)) {
+                            uint32_t x1, x2;
+                            lcp_tail2(buf + upos, buf + (uint32_t)(P + (int)la1), buf + (uint32_t)(P + (int)la2), g1, g2, x1, x2);
+                            l1 = g1 ? x1 : l1; l2 = g2 ? x2 : l2;
                         }
+                        const bool second = has_a2 || W.has0;
+                        const uint32_t ls = has_a2 ? l2 : W.len0, ns = has_a2 ? (0x10000u | (uint32_t)a2) : W.node0;
+                        uint32_t fl = kMatchMin - 1, fn = 0;
+                        if (l1 > fl) { fl = l1; fn = 0x10000u | (uint32_t)a1; }
+                        if (fl != (uint32_t)kMatchMax && second && ls > fl) { fl = ls; fn = ns; }
+                        if (fixl) { ml = fl; mn = fn; lk = a1; lkchk = k1 >> 21; lklane = la1; }
                     }
-                    if (prof) te = __builtin_readcyclecounter();
+                    is_match = ecan && !hard && ml >= (uint32_t)kMatchMin;
                     // the lazy probe under ml (src/libzling_lz.cpp:270-281, 291-316; depth 1: only the chain head is looked at)
-                    if (canm && !hard && is_match && ml < (uint32_t)kLazyLimit) {
-                        u64 Sx[NW];
-#pragma unroll
-                        for (int w = 0; w < NW; w++) Sx[w] = S[w] | (w == wv ? lane_bit : 0ull);
-                        const int lh = top_in<NW>(LK1, Sx, wv, beloweq);
-                        const bool lconf = cnt_in<NW>(LC1, Sx, wv, beloweq) > W.ld1;     // a visited slot at distance d is rewritten by the (d+1)-th insert
-                        bool veto;
-                        if (lconf) { hard = true; hcls = 3; veto = false; }
-                        else if (lh < 0 && ml == W.len) veto = W.veto1;
-                        else {
-                            const uint32_t mm = ml - 3u;
-                            const uint32_t pr = ld32u(buf + (upos + 1u + mm));
-                            const uint32_t so = lh >= 0 ? (uint32_t)(P + lh) : (W.lsrc1 & 0xFFFFFF);
-                            const uint32_t sr = ld32u(buf + (so + mm));
-                            veto = (lh >= 0 || (W.lsrc1 >> 31) != 0) && pr == sr;
+                    const bool lzq = is_match && ml < (uint32_t)kLazyLimit;
+                    const u64 lq = LK1 & rbeq;                              // tokens up to and including me with the probe's key
+                    const bool has_lh = lq != 0ull;
+                    const int lh = top_bit(lq | 1ull);
+                    const bool lconf = (uint32_t)__popcll(LC1 & rbeq) > W.ld1;   // a visited slot at distance d is rewritten by the (d+1)-th insert
+                    hard = hard || (lzq && lconf);
+                    const bool need_re = lzq && !lconf && (has_lh || ml != W.len);
+                    bool veto = W.veto1;
+                    if (__any(need_re)) {
+                        // position bytes mm+1 .. mm+4 against source bytes mm .. mm+3 of the chain head the probe sees now
+                        const uint32_t mm = need_re ? ml - 3u : 0u, mc = mm <= 12u ? mm : 0u;
+                        const Quad tq = t_q[lh];
+                        const Quad sq = has_lh ? tq : ql;
+                        uint32_t pr = byte_window(qtext, t16, mc + 1u), sr = byte_window(sq, 0u, mc);
+                        const bool far = need_re && mm > 12u;
+                        if (__any(far)) {
+                            const uint32_t so = has_lh ? (uint32_t)(P + (int)t_lane[lh]) : (W.lsrc1 & 0xFFFFFF);
+                            const uint32_t pf = ld32u(buf + (upos + 1u + (far ? mm : 0u))), sf = ld32u(buf + (far ? so + mm : upos));
+                            if (far) { pr = pf; sr = sf; }
                         }
-                        if (veto) is_match = false;
+                        if (need_re) veto = (has_lh || (W.lsrc1 >> 31) != 0) && pr == sr;
                     }
-                } else if (canm) {
-                    // levels 1-4: a start of this round in my hash slot, a rewritten ring slot or a touched lazy read set -> hard
-                    const bool kq = top_in<NW>(KM, S, wv, below) >= 0;
-                    if (kq || W.dmin <= k) { hard = true; hcls = kq ? 1 : 2; }
-                    else {
-                        is_match = W.len >= (uint32_t)kMatchMin; ml = W.len; mn = W.node;
-                        if (is_match && ml < (uint32_t)kLazyLimit) {
-                            u64 Sx[NW];
-#pragma unroll
-                            for (int w = 0; w < NW; w++) Sx[w] = S[w] | (w == wv ? lane_bit : 0ull);
-                            const bool c1 = want1 && (top_in<NW>(LK1, Sx, wv, beloweq) >= 0 || cnt_in<NW>(LC1, Sx, wv, beloweq) > W.ld1);
-                            if (c1) { hard = true; hcls = 3; }
-                            else if (want1 && W.veto1) is_match = false;
-                            else if (want2) {
-                                const bool c2 = top_in<NW>(LK2, Sx, wv, beloweq) >= 0 || cnt_in<NW>(LC2, Sx, wv, beloweq) > W.ld2;
-                                if (c2) { hard = true; hcls = 3; }
-                                else if (W.veto2) is_match = false;
-                            }
-                        }
+                    is_match = is_match && !(lzq && !lconf && veto);
+                } else {
+                    // levels 1-4: a token of this round in my hash slot, a rewritten ring slot or a touched lazy read set -> hard
+                    const bool kq = (KM & rbelow) != 0ull;
+                    hard = ecan && (kq || W.dmin <= k);
+                    ml = W.len; mn = W.node;
+                    is_match = ecan && !hard && ml >= (uint32_t)kMatchMin;
+                    const bool lzq = is_match && ml < (uint32_t)kLazyLimit;
+                    const bool c1 = want1 && ((LK1 & rbeq) != 0ull || (uint32_t)__popcll(LC1 & rbeq) > W.ld1);
+                    bool c2 = false;
+                    if (want2) {
+                        const u64 LK2 = keyrow[bufi][r_lk2], LC2 = ctxrow[bufi][lc2_r];
+                        c2 = (LK2 & rbeq) != 0ull || (uint32_t)__popcll(LC2 & rbeq) > W.ld2;
                     }
+                    // probe 2 is only looked at when probe 1 does not veto (src/libzling_lz.cpp:276-281)
+                    const bool v1 = want1 && W.veto1;
+                    hard = hard || (lzq && (c1 || (!v1 && want2 && c2)));
+                    is_match = is_match && !(lzq && (v1 || (want2 && W.veto2)));
                 }
-                if (prof) tf = __builtin_readcyclecounter();
                 // word MRU of my context after every boundary event of S up to and including mine (src/libzling_lz.cpp:172-185)
-                uint32_t ty2, tlen2;
-                if (hard) { ty2 = ty; tlen2 = tlen; }
-                else if (is_match) { ty2 = kTyMatch; tlen2 = ml; }
-                else {
-                    u64 EVx[NW], EFx[NW];
-#pragma unroll
-                    for (int w = 0; w < NW; w++) { EVx[w] = EV[w] | ((w == wv && has_ev) ? lane_bit : 0ull); EFx[w] = EFF[w] | ((w == wv && eff) ? lane_bit : 0ull); }
-                    const int e1 = top_in<NW>(EKC, EVx, wv, beloweq), e2 = top_in<NW>(EKC, EFx, wv, beloweq);
-                    const uint32_t m0 = mru[ctx];
-                    const uint32_t s0 = e1 >= 0 ? (a_ev[e1] & 0xFFFF) : (m0 & 0xFFFF);
-                    const uint32_t s1 = e2 >= 0 ? (e2 == tid ? s0b : a_s0b[e2]) : (m0 >> 16);
-                    const bool two = live && pos + 1 < ilen;
-                    ty2 = (two && s0 == cw) ? kTyW0 : ((two && s1 == cw) ? kTyW1 : kTyLit);
-                    tlen2 = ty2 == kTyLit ? 1u : 2u;
-                }
-                const bool chg = inS && (ty2 != ty || tlen2 != tlen);
-                ty = ty2; tlen = tlen2;
-                if (!hard) { mlen = ml; mnode = mn; link = lk; link_chk = lkchk; }
+                uint32_t s0 = m0c & 0xFFFF, s1 = m0c >> 16;
                 {
-                    const u64 hb = __ballot(hard && inS), cb = __ballot(chg), mb = __ballot(ty == kTyMatch && inS);
-                    a_st[tid] = ty | tlen << 8;
-                    a_succ[tid] = (uint32_t)NL;
-                    if (lane == 0) { u_hard[wv] = hb; u_chg[wv] = cb; u_mat[wv] = mb; }
-                }
-                if (prof) tg = __builtin_readcyclecounter();
-                __syncthreads();                                    // (B4)
-                u64 HB[NW], CB[NW];
-#pragma unroll
-                for (int w = 0; w < NW; w++) { HB[w] = uni64(u_hard[w]); CB[w] = uni64(u_chg[w]); MAT[w] = uni64(u_mat[w]); }
-                // cut of the round: the first hard lane of S ...
-                limit = nlive; limit_hard = false;
-#pragma unroll
-                for (int w = NW - 1; w >= 0; w--) if (HB[w]) { limit = 64 * w + (int)__builtin_ctzll(HB[w]); limit_hard = true; }
-                // ... or the end of the sub-block (src/libzling_lz.cpp:153): token j may start while opos + 1 < kSubSyms
-                {
-                    uint32_t tot = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; w++) {
-                        const u64 lm = 64 * w + 64 <= limit ? ~0ull : (64 * w >= limit ? 0ull : ((1ull << (limit - 64 * w)) - 1ull));
-                        tot += (uint32_t)__popcll(S[w] & lm) + (uint32_t)__popcll(MAT[w] & lm);
+                    const bool nm = inS && !hard && !is_match;
+                    const u64 M = nm ? (EKC & EVu & rbeq) : 0ull;
+                    bool act = M != 0ull;
+                    int e = top_bit(M | 1ull);
+                    uint32_t w = t_ev[e] & 0xFFFF;
+                    if (act) s0 = w;
+                    u64 cur = M & ~(1ull << e);
+                    for (int i = 0; i < 4; i++) {
+                        if (!__any(act)) break;
+                        const bool more = cur != 0ull;
+                        const int e2 = top_bit(cur | 1ull);
+                        const uint32_t tw = t_ev[e2] & 0xFFFF;
+                        const uint32_t pw = more ? tw : (m0c & 0xFFFF);
+                        const bool eff = !((CONDu >> e) & 1ull) || w != pw;
+                        if (act && eff) s1 = pw;
+                        act = act && !eff && more;
+                        e = e2; cur &= ~(1ull << e2); w = pw;
                     }
+                    hard = hard || act;                                     // not settled within four events of the key
+                }
+                uint32_t ty2, tlen2;
+                {
+                    const bool two = pos + 1 < ilen;
+                    const uint32_t wty = (two && s0 == cw) ? kTyW0 : ((two && s1 == cw) ? kTyW1 : kTyLit);
+                    ty2 = is_match ? kTyMatch : wty;
+                    tlen2 = is_match ? ml : (wty == kTyLit ? 1u : 2u);
+                    const bool keep = !inS || hard;
+                    ty2 = keep ? ty : ty2; tlen2 = keep ? tlen : tlen2;
+                    if (!keep) { mlen = ml; mnode = mn; link = lk; link_chk = lkchk; link_lane = lklane; }
+                }
+                hard = hard && inS;
+                const bool chg = ty2 != ty || tlen2 != tlen;
+                if (inS) t_res[rank] = (hard ? 4u : 0u) | (chg ? 8u : 0u) | (ty2 == kTyMatch ? 16u : 0u);
+                ty = ty2; tlen = tlen2;
+                if (chg) a_st[tid] = ty | tlen << 8;
+                if (__any(chg)) closure();                          // a wavefront whose lengths did not change keeps its closure
+                if (prof) td = __builtin_readcyclecounter();
+                __syncthreads();                                    // (Be)
+                u64 HB, CB;
+                {
+                    const uint32_t f = (uint32_t)lane < ntok ? t_res[lane] : 0u;
+                    HB = __ballot((f & 4u) != 0); CB = __ballot((f & 8u) != 0); MATu = __ballot((f & 16u) != 0);
+                }
+                // cut of the round: the first hard token, the 64th token ...
+                limit = (int)ntok; limit_hard = false;
+                if (HB) { limit = (int)__builtin_ctzll(HB); limit_hard = true; }
+                // ... or the end of the sub-block (src/libzling_lz.cpp:153): token r may start while opos + 1 < kSubSyms
+                {
+                    const u64 lm = limit >= 64 ? ~0ull : ((1ull << limit) - 1ull);
+                    const uint32_t tot = (uint32_t)limit + (uint32_t)__popcll(MATu & lm);
                     if ((uint32_t)opos + tot + 1u >= (uint32_t)kSubSyms) {
-                        u64 ones[NW];
-#pragma unroll
-                        for (int w = 0; w < NW; w++) ones[w] = ~0ull;
-                        const uint32_t before = cnt_in<NW>(ones, S, wv, below) + cnt_in<NW>(ones, MAT, wv, below);
-                        const u64 vb = __ballot(inS && !((uint32_t)opos + before + 1u < (uint32_t)kSubSyms));
-                        if (lane == 0) u_cut[wv] = vb;
+                        if (tid == 0) u_cut = 0;
                         __syncthreads();
-#pragma unroll
-                        for (int w = NW - 1; w >= 0; w--) {
-                            const u64 v = uni64(u_cut[w]);
-                            if (v) { const int c = 64 * w + (int)__builtin_ctzll(v); if (c <= limit) { limit = c; limit_hard = false; } }
-                        }
-                        __syncthreads();                            // u_cut is free again
+                        if (inS && !((uint32_t)opos + rank + (uint32_t)__popcll(MATu & rbelow) + 1u < (uint32_t)kSubSyms)) atomicOr(&u_cut, rbit);
+                        __syncthreads();
+                        const u64 v = uni64(u_cut);
+                        if (v) { const int c = (int)__builtin_ctzll(v); if (c <= limit) { limit = c; limit_hard = false; } }
                         if (prof) n_cutr++;
                     }
                 }
-                bool changed = false;
-#pragma unroll
-                for (int w = 0; w < NW; w++) {
-                    const u64 lm = 64 * w + 64 <= limit ? ~0ull : (64 * w >= limit ? 0ull : ((1ull << (limit - 64 * w)) - 1ull));
-                    changed = changed || (CB[w] & lm) != 0ull;
-                }
-                if (prof) { n_iter++; th = __builtin_readcyclecounter(); c_cl += tb - ta; c_a += tc - tb; c_b += td - tc; c_c1 += te - td; c_c2 += tf - te; c_c3 += tg - tf; c_lim += th - tg; }
+                const u64 lm = limit >= 64 ? ~0ull : ((1ull << limit) - 1ull);
+                const bool changed = (CB & lm) != 0ull;
+                if (prof) { n_iter++; c_dep += tb - ta; c_ev += td - tc; c_lim += __builtin_readcyclecounter() - td; }
                 if (!changed) break;
-                if (it > 2 * NL) { overflow = true; break; }        // cannot happen: every iteration fixes at least one lane of S
+                if (it > 2 * NL) { overflow = true; break; }        // cannot happen: every iteration fixes at least one token of S
             }
             if (prof) t3 = __builtin_readcyclecounter();
 
-            // ---------------- commit S below the limit
-            u64 C[NW];
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                const u64 lm = 64 * w + 64 <= limit ? ~0ull : (64 * w >= limit ? 0ull : ((1ull << (limit - 64 * w)) - 1ull));
-                C[w] = S[w] & lm;
-            }
-            const bool mine = ((C[wv] >> lane) & 1ull) != 0;
-            // who links to whom in a hash slot: the slot's head must end up being the LAST start of the round in it
-            if (mine && canm && link >= 0) atomicMin(&a_succ[link], (uint32_t)tid);
-            __syncthreads();                                        // (B5)
-            uint32_t ncom = 0, nmat = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) { ncom += (uint32_t)__popcll(C[w]); nmat += (uint32_t)__popcll(C[w] & MAT[w]); }
+            // ---------------- commit the first `limit` tokens of S
+            const u64 Cm = limit >= 64 ? ~0ull : ((1ull << limit) - 1ull);
+            const bool mine = inS && (int)rank < limit;
             if (mine) {
-                u64 ones[NW];
-#pragma unroll
-                for (int w = 0; w < NW; w++) ones[w] = ~0ull;
-                const uint32_t rank = cnt_in<NW>(ones, C, wv, below);
                 uint32_t word;
                 if (canm) {
                     // dictionary insert (src/libzling_lz.cpp:227-230); slots of a bucket are handed out in position order
                     const uint32_t head = (head0 + k_ctx + 1u) & (kRing - 1);
                     BucketT<kWide> B(dict, ctx);
                     uint32_t lslot = W.node0, pword = W.ov0;
-                    if (link >= 0) { lslot = (head0 + cnt_below_lane<NW>(CM, C, link) + 1u) & (kRing - 1); pword = (uint32_t)(P + link) | link_chk << 24; }
+                    if (link >= 0) { lslot = (head0 + (uint32_t)__popcll(CM & ((1ull << link) - 1ull)) + 1u) & (kRing - 1); pword = (uint32_t)(P + (int)link_lane) | link_chk << 24; }
                     B.suffix[head] = (uint16_t)lslot;
                     if (kWide) B.slot[head] = (u64)((uint32_t)pos | chk << 24) | (u64)pword << 32;
                     else B.offset[head] = (uint32_t)pos | chk << 24;
-                    if (a_succ[tid] >= (uint32_t)limit) B.hash[hc] = (uint16_t)head;
-                    if (!any_above<NW>(CM, C, wv, above)) heads[ctx] = (uint16_t)head;
+                    // the slot's head must end up being the LAST token of the round in it; the bucket's ring head likewise
+                    if ((KM & Cm & ~(rbelow | rbit)) == 0ull) B.hash[hc] = (uint16_t)head;
+                    if ((CM & Cm & ~(rbelow | rbit)) == 0ull) heads[ctx] = (uint16_t)head;
                     uint32_t msl = mnode;
-                    if (mnode & 0x10000u) msl = (head0 + cnt_below_lane<NW>(CM, C, (int)(mnode & 0xFFFFu)) + 1u) & (kRing - 1);
+                    if (mnode & 0x10000u) msl = (head0 + (uint32_t)__popcll(CM & ((1ull << (mnode & 63u)) - 1ull)) + 1u) & (kRing - 1);
                     word = (258u + mlen - kMatchMin) | ((head - msl) & (kRing - 1)) << 16;
                 } else word = 0;
                 if (ty == kTyW0) word = 256; else if (ty == kTyW1) word = 257; else if (ty == kTyLit) word = b_0 | ctx << 16;
                 __builtin_nontemporal_store(word, &tok[nt + rank]);
-                // MRU slots of my event key after the round: written by the key's last event
-                if (has_ev) {
-                    u64 EVc[NW], EFc[NW];
-#pragma unroll
-                    for (int w = 0; w < NW; w++) { EVc[w] = EV[w] & C[w]; EFc[w] = EFF[w] & C[w]; }
-                    if (!any_above<NW>(EKS, EVc, wv, above)) {
-                        const int e2 = top_in<NW>(EKS, EFc, wv, beloweq);
-                        const uint32_t m0e = mru[ek];
-                        mru[ek] = ew | (e2 >= 0 ? (e2 == tid ? s0b : a_s0b[e2]) : (m0e >> 16)) << 16;
-                    }
+                // MRU slots of my event key after the round: written by the key's last committed event
+                if (has_ev && (EKS & EVu & Cm & ~(rbelow | rbit)) == 0ull) {
+                    uint32_t s0, s1;
+                    ev_state(EKS & EVu & (rbelow | rbit), CONDu, m0e, t_ev, s0, s1, 64);
+                    mru[ek] = s0 | s1 << 16;
                 }
             }
             // round summary (uniform): the last committed token leads on
-            if (ncom) {
-                int lastl = 0;
-#pragma unroll
-                for (int w = 0; w < NW; w++) if (C[w]) lastl = 64 * w + top_bit(C[w]);
-                const uint32_t st = ufl(a_st[lastl]);
-                q = P + lastl + (int)(st >> 8);
+            if (limit > 0) {
+                const uint32_t ll = ufl(t_lane[limit - 1]);
+                const uint32_t st = ufl(a_st[ll]);
+                q = P + (int)ll + (int)(st >> 8);
                 prevty = st & 0xFF;
-                nt += ncom; opos += (int)(ncom + nmat);
+                nt += (uint32_t)limit; opos += limit + __popcll(MATu & Cm);
             }
             serial_next = limit_hard;
-            if (ncom == 0 && !limit_hard) overflow = true;          // cannot happen: a round commits a token or names a hard lane
-            __syncthreads();                                        // (B6) inserts, heads, MRU are visible; per-lane arrays are free again
+            if (limit == 0 && !limit_hard) overflow = true;         // cannot happen: a round commits a token or names a hard one
+            // my bits of the last iteration's buffer
+            if (dep_prev) {
+                const int bl = itn & 1;
+                atomicAnd(&keyrow[bl][dep_prev_rows & 0xFFFu], ~dep_prev);
+                atomicAnd(&ctxrow[bl][(dep_prev_rows >> 12) & 0x1FFu], ~dep_prev);
+                atomicAnd(&ekrow[bl][(dep_prev_rows >> 21) & 0x1FFu], ~dep_prev);
+            }
+            __syncthreads();                                        // (B6) inserts, heads, MRU are visible; rows and arrays are free again
             if (prof) {
                 const u64 t4 = __builtin_readcyclecounter();
                 c_p1 += t1 - t0; c_tab += t2 - t1; c_it += t3 - t2; c_com += t4 - t3; n_round++; n_pos += (u64)(q - P);
-                if (limit_hard) n_hard[0]++;
+                if (limit_hard) n_hardr++;
             }
         }
         if (nsub < kMaxSub && tid == 0) cuts[nsub] = SubCut{tok_begin, nt, (uint32_t)q, (uint32_t)opos};
@@ -747,7 +713,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     if (prof && tid == 0) {
         u64* d = a.dbg + (size_t)blk * kDbgSlots;
         d[0] = c_p1; d[1] = c_tab; d[2] = c_it; d[3] = n_round; d[4] = nt; d[5] = n_iter; d[6] = n_ser; d[7] = n_pos; d[8] = c_ser; d[9] = c_com;
-        d[10] = n_hard[0]; d[11] = n_cutr; d[12] = c_cl; d[13] = c_a; d[14] = c_b; d[15] = c_c1; d[16] = c_c2; d[17] = c_c3; d[18] = c_lim; d[19] = c_t1;
+        d[10] = n_hardr; d[11] = n_cutr; d[12] = c_dep; d[13] = c_ev; d[14] = c_lim; d[15] = c_x1; d[16] = c_x2; d[17] = c_x3;
     }
 }
 
@@ -762,7 +728,8 @@ void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks_all, hipStream_t 
         else hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);                       \
     } while (0)
     if (nw <= 2) ZLNG_WG_LAUNCH(2);
-    else ZLNG_WG_LAUNCH(4);
+    else if (nw <= 4) ZLNG_WG_LAUNCH(4);
+    else ZLNG_WG_LAUNCH(8);
 #undef ZLNG_WG_LAUNCH
 }
 

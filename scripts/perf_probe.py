@@ -60,8 +60,7 @@ if os.environ.get("ZLNG_PROFILE") == "1":
             print("blk %2d wg: %5.0f Mcyc  rounds %6d tokens %7d  positions/round %.1f iterations/round %.2f serial tokens/round %.3f cut rounds %d | cycles per round: phase1 %5.0f tables %5.0f iterate %5.0f commit %5.0f | per serial token %5.0f" % (
                 b, (d[0] + d[1] + d[2] + d[9] + d[8]) / 1e6, d[3], d[4], d[7] / r, d[5] / r, d[6] / r, d[11], d[0] / r, d[1] / r, d[2] / r, d[9] / r, d[8] / max(d[6], 1)))
             i = max(d[5], 1)
-            print("        per iteration: closure+chase %5.0f  A(+B2) %5.0f  B(+B3) %5.0f  C match/fix %5.0f  C lazy %5.0f  C mru %5.0f  B4+limit %5.0f | tables: closure+B1 %5.0f per round" % (
-                d[12] / i, d[13] / i, d[14] / i, d[15] / i, d[16] / i, d[17] / i, d[18] / i, d[19] / r))
+            print("        per iteration: chase+rank+deposit %5.0f  E (+closure) %5.0f  exchange+limit %5.0f | hard rounds %d | chase %5.0f rank+pty %5.0f deposit %5.0f" % (d[12] / i, d[13] / i, d[14] / i, d[10], d[15] / i, d[16] / i, d[17] / i))
         sys.exit(0)
     for b in range(min(nb, 4)):
         d = buf[SL * b: SL * b + 8]
