@@ -237,6 +237,8 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     u64 c_p1 = 0, c_tab = 0, c_it = 0, c_com = 0, c_ser = 0, n_round = 0, n_iter = 0, n_ser = 0, n_hardr = 0, n_pos = 0, n_cutr = 0;
     u64 c_dep = 0, c_ev = 0, c_lim = 0, c_x1 = 0, c_x2 = 0, c_x3 = 0;
     const bool prof = kProf && a.dbg != nullptr;
+    u64 c_mk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mk_last = 0;
+#define ZLNG_MK(i) do { if (prof) { const u64 t_ = __builtin_readcyclecounter(); c_mk[i] += t_ - mk_last; mk_last = t_; } } while (0)
 
     while (q < ilen && !overflow) {                  // ---- one sub-block (one EncodeImpl call)
         const uint32_t lvl = kAllL0 ? 0u : (uint32_t)a.lvl_sched[blk * kMaxSub + (nsub < kMaxSub ? nsub : kMaxSub - 1)];
@@ -353,20 +355,27 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
             uint32_t mlen = W.len, mnode = W.node;                  // mnode: ring slot, or 0x10000 | rank for a token of this round
             int link = -1;                                          // rank of my in-slot predecessor among the tokens of this round (-1: the snapshot's head)
             uint32_t link_chk = 0, link_lane = 0;
-            if (prof) t1 = __builtin_readcyclecounter();
+            if (prof) { t1 = __builtin_readcyclecounter(); mk_last = t1; }
 
             // ---------------- exact table rows of the round's keys (open addressing: a row belongs to ONE key)
-            uint32_t r_key = kWgRows;
-            if (canm) {
-                uint32_t slot = wg_key_ix(key);
-                while (true) {
-                    const uint32_t old = atomicCAS(&ht_key[slot], kWgEmpty, key);
-                    if (old == kWgEmpty || old == key) break;
-                    slot = (slot + 1u) & (kWgRows - 1);
+            auto claim_row = [&](uint32_t k21, bool want) -> uint32_t {
+                uint32_t slot = wg_key_ix(k21), r = kWgRows;
+                bool go = want;
+                while (__any(go)) {
+                    if (go) {
+                        const uint32_t old = atomicCAS(&ht_key[slot], kWgEmpty, k21);
+                        if (old == kWgEmpty || old == k21) { r = slot; go = false; }
+                        else slot = (slot + 1u) & (kWgRows - 1);
+                    }
                 }
-                r_key = slot;
-            }
+                return r;
+            };
+            const uint32_t r_key = claim_row(key, canm);
+            // the lazy probes' keys get rows too (one that no position of the window has stays empty)
+            const uint32_t r_lk1 = claim_row(W.lkey1, canm && want1);
+            const uint32_t r_lk2 = want2 ? claim_row(W.lkey2, canm) : (uint32_t)kWgRows;
             a_st[tid] = ty | tlen << 8;
+            ZLNG_MK(0);
 
             // closure of the token chain inside this wavefront: after the loop every lane knows the positions of its own
             // wavefront its chain passes (mask) and where the chain leaves the wavefront (nxg, a global lane index)
@@ -385,25 +394,12 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 c_exit[tid] = nxg; c_mask[tid] = mk;
             };
             closure();
+            ZLNG_MK(1);
             __syncthreads();                                        // (B1) rows claimed, a_st and the closure are in LDS
-            // rows of my lazy probes' keys (the sink row if no position of the window has that key)
-            auto find_row = [&](uint32_t k21, bool want) -> uint32_t {
-                uint32_t slot = wg_key_ix(k21), r = kWgRows;
-                bool go = want;
-                while (__any(go)) {
-                    if (go) {
-                        const uint32_t v = ht_key[slot];
-                        if (v == k21) { r = slot; go = false; }
-                        else if (v == kWgEmpty) go = false;
-                        else slot = (slot + 1u) & (kWgRows - 1);
-                    }
-                }
-                return r;
-            };
-            const uint32_t r_lk1 = find_row(W.lkey1, canm && want1);
-            const uint32_t r_lk2 = want2 ? find_row(W.lkey2, canm) : (uint32_t)kWgRows;
+            ZLNG_MK(2);
             const uint32_t ctx_r = canm ? ctx : 256u, lc1_r = (canm && want1) ? lctx1 : 256u, lc2_r = (canm && want2) ? lctx2 : 256u;
             const uint32_t ek_r = live ? ek : 256u, ekc_r = live ? ctx : 256u;
+            ZLNG_MK(3);
             if (prof) t2 = __builtin_readcyclecounter();
 
             // ---------------- iterate to the fixed point
@@ -421,19 +417,26 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 const int bufi = it & 1;
                 u64 ta = 0, tb = 0, tc = 0, td = 0;
                 if (prof) ta = __builtin_readcyclecounter();
-                // chase: one hop per wavefront (every wavefront walks it; the result is uniform)
+                // chase: one hop per wavefront (every wavefront walks it; the result is uniform).  The dependent chain -- entry lane of
+                // the next wavefront the chain reaches -- is NW LDS reads with the address kept in a vector register; the masks of the
+                // entries follow in parallel.
                 u64 S[NW];
-#pragma unroll
-                for (int w = 0; w < NW; w++) S[w] = 0ull;
                 {
-                    int e = 0;
-                    for (int hop = 0; hop < NW && e < nlive; hop++) {
-                        const int ew_ = e >> 6;
-                        const u64 mk = uni64(c_mask[e]);
-                        const int nxe = (int)ufl(c_exit[e]);
+                    uint32_t ev[NW];
+                    uint32_t e = 0;
 #pragma unroll
-                        for (int w = 0; w < NW; w++) if (w == ew_) S[w] = mk;
-                        e = nxe;
+                    for (int hop = 0; hop < NW; hop++) { ev[hop] = e; e = c_exit[e < (uint32_t)nlive ? e : 0u] | (e < (uint32_t)nlive ? 0u : 0x8000u); }
+                    u64 mv[NW];
+#pragma unroll
+                    for (int hop = 0; hop < NW; hop++) mv[hop] = c_mask[ev[hop] < (uint32_t)nlive ? ev[hop] : 0u];
+#pragma unroll
+                    for (int w = 0; w < NW; w++) S[w] = 0ull;
+#pragma unroll
+                    for (int hop = 0; hop < NW; hop++) {
+                        const uint32_t eh = ufl(ev[hop]);
+                        const u64 mk = uni64(mv[hop]);
+#pragma unroll
+                        for (int w = 0; w < NW; w++) if (eh < (uint32_t)nlive && (int)(eh >> 6) == w) S[w] = mk;
                     }
                 }
                 u64 tx1 = 0, tx2 = 0;
@@ -476,7 +479,11 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 }
                 if (prof) { tb = __builtin_readcyclecounter(); c_x1 += tx1 - ta; c_x2 += tx2 - tx1; c_x3 += tb - tx2; }
                 __syncthreads();                                    // (Bb) rows and token arrays of this iteration are complete
-                if (it == 0 && canm) ht_key[r_key] = kWgEmpty;      // every lookup of the round is done
+                if (it == 0 && canm) {                              // every row of the round is claimed: the keys can go
+                    ht_key[r_key] = kWgEmpty;
+                    if (want1) ht_key[r_lk1] = kWgEmpty;
+                    if (want2) ht_key[r_lk2] = kWgEmpty;
+                }
                 // my bits of the PREVIOUS iteration's buffer go now (nobody reads it any more, nobody writes it before the next barrier)
                 if (dep_prev) {
                     atomicAnd(&keyrow[bufi ^ 1][dep_prev_rows & 0xFFFu], ~dep_prev);
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     const uint32_t f = (uint32_t)lane < ntok ? t_flag[lane] : 0u;
                     EVu = __ballot((f & 1u) != 0); CONDu = __ballot((f & 3u) == 3u);
                 }
-                if (prof) tc = __builtin_readcyclecounter();
+                if (prof) { tc = __builtin_readcyclecounter(); mk_last = tc; }
 
                 // ---- E: my token given the tokens of S before me.  Straight-line: every lane computes, the tokens of S keep the result
                 // (divergent branches cost a lone wavefront more than the selects do); only rare work sits behind uniform branches.
@@ -535,6 +542,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                         if (fl != (uint32_t)kMatchMax && second && ls > fl) { fl = ls; fn = ns; }
                         if (fixl) { ml = fl; mn = fn; lk = a1; lkchk = k1 >> 21; lklane = la1; }
                     }
+                    ZLNG_MK(4);
                     is_match = ecan && !hard && ml >= (uint32_t)kMatchMin;
                     // the lazy probe under ml (src/libzling_lz.cpp:270-281, 291-316; depth 1: only the chain head is looked at)
                     const bool lzq = is_match && ml < (uint32_t)kLazyLimit;
@@ -578,6 +586,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     hard = hard || (lzq && (c1 || (!v1 && want2 && c2)));
                     is_match = is_match && !(lzq && (v1 || (want2 && W.veto2)));
                 }
+                ZLNG_MK(5);
                 // word MRU of my context after every boundary event of S up to and including mine (src/libzling_lz.cpp:172-185)
                 uint32_t s0 = m0c & 0xFFFF, s1 = m0c >> 16;
                 {
@@ -601,6 +610,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     }
                     hard = hard || act;                                     // not settled within four events of the key
                 }
+                ZLNG_MK(6);
                 uint32_t ty2, tlen2;
                 {
                     const bool two = pos + 1 < ilen;
@@ -616,9 +626,12 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 if (inS) t_res[rank] = (hard ? 4u : 0u) | (chg ? 8u : 0u) | (ty2 == kTyMatch ? 16u : 0u);
                 ty = ty2; tlen = tlen2;
                 if (chg) a_st[tid] = ty | tlen << 8;
-                if (__any(chg)) closure();                          // a wavefront whose lengths did not change keeps its closure
+                ZLNG_MK(7);
+                if (__any(chg)) closure();
+                ZLNG_MK(8);                          // a wavefront whose lengths did not change keeps its closure
                 if (prof) td = __builtin_readcyclecounter();
                 __syncthreads();                                    // (Be)
+                ZLNG_MK(9);
                 u64 HB, CB;
                 {
                     const uint32_t f = (uint32_t)lane < ntok ? t_res[lane] : 0u;
@@ -714,6 +727,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
         u64* d = a.dbg + (size_t)blk * kDbgSlots;
         d[0] = c_p1; d[1] = c_tab; d[2] = c_it; d[3] = n_round; d[4] = nt; d[5] = n_iter; d[6] = n_ser; d[7] = n_pos; d[8] = c_ser; d[9] = c_com;
         d[10] = n_hardr; d[11] = n_cutr; d[12] = c_dep; d[13] = c_ev; d[14] = c_lim; d[15] = c_x1; d[16] = c_x2; d[17] = c_x3;
+        for (int i = 0; i < 6; i++) d[18 + i] = c_mk[i] << 32 >> 32 | c_mk[6 + i] << 32;
     }
 }
 

@@ -195,7 +195,8 @@ int alloc_token_pools(zlng_ctx* c, uint32_t tok_cap) {
 void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uint32_t blk0) {
     static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
     static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
-    static const int pf_waves = getenv("ZLNG_PF_WAVES") ? std::min(3, std::max(1, atoi(getenv("ZLNG_PF_WAVES")))) : 1;
+    static const int pf_env = getenv("ZLNG_PF_WAVES") ? atoi(getenv("ZLNG_PF_WAVES")) : -1;     // the wg parser: prefetch of the next window only on request (> 0): measured slower
+    static const int pf_waves = pf_env < 0 ? 1 : std::min(3, std::max(1, pf_env));
     static const int pipe_lead = getenv("ZLNG_PIPE_LEAD") ? atoi(getenv("ZLNG_PIPE_LEAD")) : 2;
     static const int pipe_pf = getenv("ZLNG_PIPE_PF") ? atoi(getenv("ZLNG_PIPE_PF")) : 1;
     static const int settle_pf = getenv("ZLNG_SETTLE_PF") ? atoi(getenv("ZLNG_SETTLE_PF")) : 1;
@@ -205,7 +206,7 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     static const int wg_waves = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
     launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, c->parser_kind >= 2 && c->level == 0);
     timer_mark(c, "dict_reset");
-    if (c->parser_kind == 3) launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves);
+    if (c->parser_kind == 3) { pa.pf_waves = pf_env > 0 ? 1 : 0; launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves); }
     else if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
     else if (c->parser_kind == 0) { pa.pf_ahead = pipe_lead; pa.pf_waves = pipe_pf; launch_rolz_parse_pipe(pa, nb, c->stream, c->level == 0); }
     else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so

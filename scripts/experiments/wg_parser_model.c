@@ -54,7 +54,7 @@ static struct {
     long hist_it[16];
 } st;
 
-static int precise_risk = 1, only_s = 0, max_tok = 1 << 30;
+static int precise_risk = 1, only_s = 0, max_tok = 1 << 30, guess_mru = 0;
 static int ring_dist(int node, int head0) { return (node - head0 - 1) & (ZO_RING - 1); }
 
 /* Read-only evaluation of `pos` as a token start against the dictionary as it is now (phase 1). */
@@ -208,6 +208,9 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 else { l->sp_match = 0; l->sp_len = 3; l->dmin = ZO_RING - 1; }
                 l->ty = l->sp_match ? TY_MATCH : TY_LIT;
                 l->mlen = l->sp_len; l->tlen = l->sp_match ? l->sp_len : 1;
+                if (guess_mru && !l->sp_match && pos + 1 < ilen) {       /* first guess from the MRU slots at the start of the round */
+                    if (mru[l->ctx][0] == l->cw) { l->ty = TY_W0; l->tlen = 2; } else if (mru[l->ctx][1] == l->cw) { l->ty = TY_W1; l->tlen = 2; }
+                }
                 l->mnode_slot = l->sp_node; l->link_lane = -1;
             }
             /* ---- iterate to the fixed point */
@@ -405,6 +408,7 @@ int main(int argc, char** argv) {
     if (argc > 6) precise_risk = atoi(argv[6]);
     if (argc > 7) only_s = atoi(argv[7]);
     if (argc > 8) max_tok = atoi(argv[8]);
+    if (argc > 9) guess_mru = atoi(argv[9]);
     FILE* f = fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 2; }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     if (n > maxb) n = maxb;

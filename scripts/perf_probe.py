@@ -61,6 +61,9 @@ if os.environ.get("ZLNG_PROFILE") == "1":
                 b, (d[0] + d[1] + d[2] + d[9] + d[8]) / 1e6, d[3], d[4], d[7] / r, d[5] / r, d[6] / r, d[11], d[0] / r, d[1] / r, d[2] / r, d[9] / r, d[8] / max(d[6], 1)))
             i = max(d[5], 1)
             print("        per iteration: chase+rank+deposit %5.0f  E (+closure) %5.0f  exchange+limit %5.0f | hard rounds %d | chase %5.0f rank+pty %5.0f deposit %5.0f" % (d[12] / i, d[13] / i, d[14] / i, d[10], d[15] / i, d[16] / i, d[17] / i))
+            mk = [d[18 + k] & 0xFFFFFFFF for k in range(6)] + [d[18 + k] >> 32 for k in range(6)]
+            print("        tables per round: rows(CAS) %5.0f closure %5.0f B1-wait %5.0f find_row %5.0f | E per iteration: rows+fix %5.0f lazy %5.0f mru %5.0f finish %5.0f closure-if-changed %5.0f Be-wait %5.0f (32-bit counters: may wrap)" % (
+                mk[0] / r, mk[1] / r, mk[2] / r, mk[3] / r, mk[4] / i, mk[5] / i, mk[6] / i, mk[7] / i, mk[8] / i, mk[9] / i))
         sys.exit(0)
     for b in range(min(nb, 4)):
         d = buf[SL * b: SL * b + 8]
