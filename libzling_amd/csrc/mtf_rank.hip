@@ -484,6 +484,211 @@ __global__ __launch_bounds__(256) void k_mtf_replay(MtfArgs a) {
     if (lane < kk) run[lane] = (uint8_t)ranks;
 }
 
+// ------------------------------------------------------------------------------ K2d, front / back form (ZLNG_MTF=front: exact, NOT the default)
+// mtfnext (src/tables/gen.py:52-56) splits the table: ranks 0..20 swap with their LEFT NEIGHBOUR (mtfnext[i] = i - 1), so a literal
+// whose symbol is among the first 21 entries -- the FRONT -- moves only inside the front; ranks 23..255 move only inside the BACK
+// (mtfnext[23] = 21, mtfnext[i] >= 21 from there on); the two parts meet in exactly two ranks: 21 (-> 19) and 22 (-> 20).  Between
+// such COUPLING literals the front and the back evolve independently of each other, and which part a literal belongs to is a
+// property of its symbol (is it in the front SET, which only a coupling changes).  One wavefront per context walks a tile of 64
+// literals in two interleaved passes:
+//   back pass   the tile's literals are classified in parallel against the front set (a byte table in LDS); every literal outside it
+//               is ranked and applied to the back in order (register table, v_readlane / v_writelane); its rank is recorded;
+//   front pass  the front lives in lanes 0..20 of one VGPR whose other lanes hold values no byte equals, so the neighbour-swap step
+//               needs NO test at all: a literal that is not in the front is a no-op by itself.  Five VALU instructions per literal
+//               (scripts/ubench/fstep.hip: 11.7 ns against 17.1 for the tested step; the s_nop is the gfx9 wait state between a
+//               VALU write and a DPP read of the same register -- measured: without it the table comes out wrong), sixteen literals
+//               per asm statement straight from the scalar registers the tile was loaded into.
+// A coupling literal stops the front pass at its position, exchanges the two symbols and re-classifies the rest of the tile.
+// MEASURED (round 3, scripts/ctx_probe.py): the test-free step is 11.7 ns per literal, but the boundary at rank 21 lies inside the
+// active zone of real tables -- 1.9 % of the blank context's literals on the benchmark text and 3 % on source text are couplings
+// (80 % of all its literals outside the front), each costs a partial group in loop form on both sides (~0.5 us), and a literal
+// outside the front ~0.3 us of compiler-generated v_readlane / v_writelane code: 37 ns per literal against k_mtf_dense's 19 on the
+// benchmark text, 125 against 62 on source text.  Kept as a cross-check of the rank stage and as the record of the experiment.
+// The chain carries only the tables forward; k_mtf_replay_front recomputes the front literals' ranks per tile from the front's
+// snapshot (and the recorded back ranks: a 21 / 22 among them tells it where a symbol entered the front).
+#define ZLNG_F_STEP(PK, B)                                                                                      \
+    "v_cmp_ne_u32_sdwa vcc, %[" #PK "], %[tf] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
+    "s_nop 0\n\t"                                                                                               \
+    "v_mov_b32_dpp %[up], %[tf] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_cmp_eq_u32_sdwa %[m1], %[" #PK "], %[up] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                        \
+    "v_cndmask_b32_dpp %[tf], %[tf], %[tf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                      \
+    "v_cndmask_b32_e64 %[tf], %[tf], %[up], %[m1]\n\t"
+#define ZLNG_F_WORD(PK) ZLNG_F_STEP(PK, 0) ZLNG_F_STEP(PK, 1) ZLNG_F_STEP(PK, 2) ZLNG_F_STEP(PK, 3)
+// sixteen literals = four literal registers
+#define ZLNG_F_GROUP(A, B, C, D)                                                                                \
+    asm volatile(ZLNG_F_WORD(pa) ZLNG_F_WORD(pb) ZLNG_F_WORD(pc) ZLNG_F_WORD(pd)                                \
+                 : [tf] "+v"(tf), [up] "+v"(up), [m1] "=&s"(m1_)                                                \
+                 : [pa] "s"(A), [pb] "s"(B), [pc] "s"(C), [pd] "s"(D)                                           \
+                 : "vcc")
+// one literal held in a scalar register
+#define ZLNG_F_ONE(C)                                                                                           \
+    asm volatile("v_cmp_ne_u32_e32 vcc, %[c], %[tf]\n\t"                                                        \
+                 "s_nop 0\n\t"                                                                                  \
+                 "v_mov_b32_dpp %[up], %[tf] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                         \
+                 "v_cmp_eq_u32_e64 %[m1], %[c], %[up]\n\t"                                                      \
+                 "v_cndmask_b32_dpp %[tf], %[tf], %[tf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"         \
+                 "v_cndmask_b32_e64 %[tf], %[tf], %[up], %[m1]\n\t"                                             \
+                 : [tf] "+v"(tf), [up] "+v"(up), [m1] "=&s"(m1_)                                                \
+                 : [c] "s"(C)                                                                                   \
+                 : "vcc")
+
+constexpr uint32_t kFront = 21;                      // table positions 0..20
+
+__global__ __launch_bounds__(64) void k_mtf_front(MtfArgs a) {
+    __shared__ uint8_t isf[256];                     // 1: the symbol is in the front
+    const uint32_t ctx = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (a.skip && a.skip[ctx]) {                                       // ranked elsewhere: only tell the replay to keep off
+        const uint32_t tiles = (a.ctx_total[ctx] + 63u) >> 6;
+        for (uint32_t t = lane; t < tiles; t += 64) a.tile_kk[(a.ctx_off[ctx] >> 6) + t] = 0;
+        return;
+    }
+    uint8_t* st = a.state + ctx * 256;
+    const uint32_t poison = 0x100u | lane;
+    const uint32_t s0 = st[lane];
+    uint32_t tf = lane < kFront ? s0 : poison;       // the front: lanes 0..20
+    uint32_t t0 = lane < kFront ? poison : s0;       // the back: lanes 21..63 of t0, then t1 .. t3 (lane l of t[r] = table[64 r + l])
+    uint32_t t1 = st[64 + lane], t2 = st[128 + lane], t3 = st[192 + lane];
+    for (uint32_t i = lane; i < 256; i += 64) isf[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane < kFront) isf[s0] = 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+
+    uint32_t up = 0xFFFFFFFFu;                       // tf shifted down one lane; lane 63 is never written
+    uint64_t m1_;
+    const unsigned long long tstart = __builtin_readcyclecounter();
+    unsigned long long n_nf = 0, n_cp = 0;
+    uint8_t* run = a.lit_byte + a.ctx_off[ctx];     // 64-byte aligned (k_ctx_offsets)
+    uint8_t* nfr = a.nfr + a.ctx_off[ctx];
+    uint8_t* snap = a.snap + a.ctx_off[ctx];
+    uint8_t* tile_kk = a.tile_kk + (a.ctx_off[ctx] >> 6);
+    const uint32_t n = a.ctx_total[ctx];
+    typedef uint32_t Tile16 __attribute__((ext_vector_type(16)));
+
+    auto back_get = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
+        switch (i >> 6) { case 0: return rdl(t0, i & 63); case 1: return rdl(t1, i & 63); case 2: return rdl(t2, i & 63); default: return rdl(t3, i & 63); }
+    };
+    auto back_set = [&](uint32_t i, uint32_t val) __attribute__((always_inline)) {
+        switch (i >> 6) { case 0: wrl(t0, val, i & 63); break; case 1: wrl(t1, val, i & 63); break; case 2: wrl(t2, val, i & 63); break; default: wrl(t3, val, i & 63); break; }
+    };
+
+    Tile16 pk, pkn;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pk) : "s"(run));          // first tile
+    // The per-lane copy of a tile is loaded one tile ahead by hand: vector memory operations retire in order and stores count too, so
+    // the wait for it may leave exactly the two stores issued behind it (snapshot, back ranks) in flight.  (Left to the compiler the
+    // loop waits for vmcnt(0) at its head, i.e. for the previous tile's stores to be acknowledged: 1.7 us per tile.)
+    uint32_t vn;
+    asm volatile("global_load_ubyte %0, %1, %2" : "=v"(vn) : "v"(lane), "s"(run) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(vn));
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t cnt = n - base < 64u ? n - base : 64u;
+        const uint32_t v = vn;                       // the tile's 64 literals, one per lane; pk holds the same bytes in sixteen SGPRs
+        {
+            const uint8_t* nptr = run + base + 64;   // next tile (the pools leave one tile of read-ahead behind the last run)
+            asm volatile("global_load_ubyte %0, %1, %2" : "=v"(vn) : "v"(lane), "s"(nptr) : "memory");
+        }
+        snap[base + lane] = (uint8_t)tf;            // the front at the start of the tile, for the replay (lanes >= 21: anything)
+        uint32_t nfv = 0;                            // lane k: rank of literal k if it was outside the front when it came
+        const bool valid = lane < cnt;
+        uint64_t nf = __ballot(valid && isf[v] == 0);
+        {   // next tile's scalar copy: issued behind the classification's LDS wait, awaited at the end of the tile
+            const uint8_t* nptr = run + base + 64;
+            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(pkn) : "s"(nptr));
+        }
+        uint32_t fpos = 0;
+        // literals [fpos, to) through the front
+        auto front_advance = [&](uint32_t to) __attribute__((always_inline)) {
+            while (fpos < to) {
+                if ((fpos & 15u) == 0u && fpos + 16u <= to) {
+                    switch (fpos >> 4) {
+                        case 0: ZLNG_F_GROUP(pk[0], pk[1], pk[2], pk[3]); break;
+                        case 1: ZLNG_F_GROUP(pk[4], pk[5], pk[6], pk[7]); break;
+                        case 2: ZLNG_F_GROUP(pk[8], pk[9], pk[10], pk[11]); break;
+                        default: ZLNG_F_GROUP(pk[12], pk[13], pk[14], pk[15]); break;
+                    }
+                    fpos += 16;
+                } else {
+                    const uint32_t c = rdl(v, fpos);
+                    ZLNG_F_ONE(c);
+                    fpos++;
+                }
+            }
+        };
+        while (nf) {
+            const uint32_t k = (uint32_t)__builtin_ctzll(nf);
+            const uint32_t c = rdl(v, k);
+            // rank = position of c in the back
+            const uint64_t m0 = __ballot(t0 == c);
+            uint32_t i;
+            if (m0) i = (uint32_t)__builtin_ctzll(m0);
+            else {
+                const uint64_t b1 = __ballot(t1 == c), b2 = __ballot(t2 == c), b3 = __ballot(t3 == c);
+                i = b1 ? 64 + (uint32_t)__builtin_ctzll(b1) : (b2 ? 128 + (uint32_t)__builtin_ctzll(b2) : 192 + (uint32_t)__builtin_ctzll(b3));
+            }
+            wrl(nfv, i, k);
+            n_nf++;
+            if (i <= kFront + 1) {
+                n_cp++;
+                // coupling (rank 21 -> 19, 22 -> 20): the front must have seen every literal before this one
+                front_advance(k);
+                fpos = k + 1;                        // (the coupling literal itself is not a front literal)
+                const uint32_t j = i - 2;
+                const uint32_t d = rdl(tf, j);
+                wrl(tf, c, j);
+                wrl(t0, d, i);
+                if (lane == 0) { isf[c] = 1; isf[d] = 0; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                nf = __ballot(valid && isf[v] == 0) & ~((2ull << k) - 1ull);      // the front set changed: classify the rest again
+            } else {
+                const uint32_t nx = mtf_next_fast(i);                  // >= 21: stays in the back
+                const uint32_t d = back_get(nx);
+                back_set(i, d);
+                back_set(nx, c);
+                nf &= nf - 1ull;
+            }
+        }
+        front_advance(cnt);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pkn));
+        pk = pkn;
+        nfr[base + lane] = (uint8_t)nfv;             // (whole tiles: the run's padding takes the surplus of its last one)
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(vn));
+        if (cnt < 64u && lane == 0) tile_kk[base >> 6] = (uint8_t)cnt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.dbg && lane == 0) { a.dbg[ctx] = __builtin_readcyclecounter() - tstart; a.dbg[256 + ctx] = n_nf | n_cp << 32; }
+    st[lane] = (uint8_t)(lane < kFront ? tf : t0); st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
+}
+
+// Ranks of every tile from the front's snapshot at its start: literals outside the front carry their rank already (nfr != 0;
+// a 21 / 22 puts the symbol into the front at 19 / 20), front literals take the recording form of the neighbour-swap step.
+__global__ __launch_bounds__(256) void k_mtf_replay_front(MtfArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t end = (size_t)a.ctx_off[255] + (((size_t)a.ctx_total[255] + 63) & ~(size_t)63);
+    if (tile * 64 >= end) return;
+    const uint32_t kk = a.tile_kk[tile];
+    if (kk == 0) return;
+    const uint32_t sv = a.snap[tile * 64 + lane];
+    uint32_t t0 = lane < kFront ? sv : (0x100u | lane);
+    uint8_t* run = a.lit_byte + tile * 64;
+    const uint32_t v = run[lane], nv = a.nfr[tile * 64 + lane];
+    uint32_t ranks = 0;
+    for (uint32_t k = 0; k < kk; k++) {
+        const uint32_t c = rdl(v, k), r = rdl(nv, k);
+        uint32_t i;
+        if (r) {
+            i = r;
+            if (r <= kFront + 1) wrl(t0, c, r - 2);
+        } else {
+            uint64_t m0, m1_;
+            uint32_t cv;
+            ZLNG_MTF_FAST(k, m0);
+        }
+        wrl(ranks, i, k);
+    }
+    if (lane < kk) run[lane] = (uint8_t)ranks;
+}
+
 // The stage in three launches, so the host can time the serial chain (the kernel the roofline line is about) by itself.
 void launch_lit_partition(const MtfArgs& a, hipStream_t s) {
     const dim3 tiles((unsigned)(a.tok_cap / kLitTile), a.nblocks);
@@ -494,11 +699,15 @@ void launch_lit_partition(const MtfArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_ctx_offsets, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_lit_tiles<kModeScatter>, tiles, dim3(64), 0, s, a);
 }
-void launch_mtf_chain(const MtfArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_mtf_dense, dim3(256), dim3(64), 0, s, a); }
+void launch_mtf_chain(const MtfArgs& a, hipStream_t s) {
+    if (a.front_split) hipLaunchKernelGGL(k_mtf_front, dim3(256), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_mtf_dense, dim3(256), dim3(64), 0, s, a);
+}
 void launch_mtf_finish(const MtfArgs& a, hipStream_t s) {
     const dim3 tiles((unsigned)(a.tok_cap / kLitTile), a.nblocks);
     const size_t max_tiles = ((size_t)a.nblocks * a.tok_cap + 256 * 64) / 64;
-    hipLaunchKernelGGL(k_mtf_replay, dim3((unsigned)((max_tiles + 3) / 4)), dim3(256), 0, s, a);
+    if (a.front_split) hipLaunchKernelGGL(k_mtf_replay_front, dim3((unsigned)((max_tiles + 3) / 4)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_mtf_replay, dim3((unsigned)((max_tiles + 3) / 4)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_lit_tiles<kModeGather>, tiles, dim3(64), 0, s, a);
 }
 

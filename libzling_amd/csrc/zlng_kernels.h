@@ -48,6 +48,9 @@ struct MtfArgs {
     uint8_t*        snap;      // table front (64 B) at the start of every 64-literal tile of lit_byte (same indexing)
     uint8_t*        tile_kk;   // per tile: literals whose ranks k_mtf_replay computes from the snapshot (0 = none)
     const uint8_t*  skip;      // optional [256]: contexts k_mtf_dense leaves alone (the measured host-chain alternative, zlng_api.hip)
+    uint8_t*        nfr;       // front / back form of the chain: rank of every literal that was outside the table front when it came (else 0)
+    unsigned long long* dbg;   // optional [512]: cycles and non-front literals per context (ZLNG_PROFILE=1 with >= 22 blocks)
+    int             front_split; // 0: k_mtf_dense + k_mtf_replay (default), 1: k_mtf_front + k_mtf_replay_front (ZLNG_MTF=front; exact, measured slower)
 };
 void launch_lit_partition(const MtfArgs& a, hipStream_t s);   // literals -> one dense run per context
 void launch_mtf_chain(const MtfArgs& a, hipStream_t s);       // k_mtf_dense: the serial chains
