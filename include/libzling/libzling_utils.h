@@ -54,7 +54,7 @@ private:
 };
 
 struct FileInputter : public Inputter {
-    explicit FileInputter(FILE* fp) : fp_(fp), consumed_(0) {}
+    FileInputter(FILE* fp) : fp_(fp), consumed_(0) {}
     size_t GetData(unsigned char* buf, size_t len);
     bool IsEnd();
     bool IsErr();
@@ -66,7 +66,7 @@ private:
 };
 
 struct FileOutputter : public Outputter {
-    explicit FileOutputter(FILE* fp) : fp_(fp), produced_(0) {}
+    FileOutputter(FILE* fp) : fp_(fp), produced_(0) {}
     size_t PutData(unsigned char* buf, size_t len);
     bool IsErr();
     size_t GetOutputSize();

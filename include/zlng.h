@@ -147,7 +147,9 @@ int zlng_decode_blocks_device(zlng_ctx*, const void* d_in, size_t in_len, size_t
 int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
 
 /* Environment read when a context is created (testing / measurement aids; none of them changes the bytes produced):
- *   ZLNG_PARSER=serial|pipe       cross-check forms of the block parser (default: the single-wavefront speculative parser)
+ *   ZLNG_PARSER=wave|serial|pipe  cross-check forms of the block parser (default: the workgroup-wide window parser, rolz_wg.hip;
+ *                                 wave = the one-wavefront parser of rounds 1-2); ZLNG_WG_WAVES=2|4|8: wavefronts per block of the default
+ *   ZLNG_MTF=front                the front / back form of the rank chain (exact, measured slower; default: k_mtf_dense)
  *   ZLNG_TOK_CAP=<words>          token words per block the pools start with (they grow once on overflow)
  *   ZLNG_HOST_RANK_CONTEXTS=<k>   MEASURED ALTERNATIVE, off by default: the k longest rank chains of a call are walked
  *                                 by host threads (literal runs over PCIe and back) while the device walks the others.
@@ -159,7 +161,19 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *   ZLNG_DEBUG_PACK_LDS=<bytes>   extra dynamic LDS for the bit packer's launch (occupancy experiments)
  * (The C++ shim reads ZLNG_DEVICE, ZLNG_DEVICES, ZLNG_BATCH_BLOCKS and ZLNG_PIPELINE: INTEGRATION.md.  The build reads
  *  ZLNG_HIPCC_FLAGS and ZLNG_BUILD_FORCE (__graft_entry__.py); bench.py reads ZLNG_ENWIK9 / ZLNG_ENWIK8 (a real enwik file
- *  to use instead of the generator) and ZLNG_BENCH_ONE_DEVICE (all ranks on device 0, collectives over gloo: a test hook).) */
+ *  to use instead of the generator) and ZLNG_BENCH_ONE_DEVICE (all ranks on device 0, collectives over gloo: a test hook);
+ *  scripts/sanitize.sh sets ZLNG_ORACLE_SO (the ASan build of the oracle), ZLNG_NO_REF, ZLNG_DEMO, ZLNG_HIP_SO (another build of libzlng_hip.so) and ZLNG_SYSTEM_HIP (the ASan build of zling_demo) for the tests.) */
+
+/* Test hooks (used by tests/ and scripts/ only; no stability promise):
+ *   zlng_debug_fetch     copy an internal per-block buffer of the last encode call to the host (what: 0 tokens, 1 cuts, 2 freq,
+ *                        3 lens, 4 olen, 5 ntok/nsub, 6 codes, 7 sub-block output offsets, 8 literals per context)
+ *   zlng_debug_lengths   run K4 (code lengths + canonical codes) on caller-supplied rows of 546 counts
+ *   zlng_debug_passes    parse passes the last encode call needed (1 = no level-schedule repair, no pool growth)
+ *   zlng_debug_counters  kDbgSlots (24) profile counters per block of the last parse (ZLNG_PROFILE=1) */
+int zlng_debug_fetch(zlng_ctx*, int what, int blk, void* dst, size_t bytes);
+int zlng_debug_lengths(zlng_ctx*, const uint32_t* freq, int nrows, uint8_t* lens, uint16_t* codes);
+int zlng_debug_passes(zlng_ctx*);
+int zlng_debug_counters(zlng_ctx*, unsigned long long* out, int nblocks);
 
 /* The hipStream_t the context launches on (as void*), for callers that need to order work. */
 void* zlng_stream(zlng_ctx*);

@@ -33,7 +33,7 @@ def _preload_torch_hip_runtime():
     process-wide one before libzlng_hip.so is opened (a no-op if torch is already imported)."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("ZLNG_SYSTEM_HIP") == "1":     # ZLNG_SYSTEM_HIP=1: torch-free tools on /opt/rocm's runtime
         return
     spec = importlib.util.find_spec("torch")
     if spec is None or not spec.origin:
@@ -56,7 +56,8 @@ def lib():
             raise ImportError("libzlng_hip.so is not built: run `python -m libzling_amd.build` "
                               "(there is no fallback implementation)")
         _preload_torch_hip_runtime()
-        L = C.CDLL(HIP_SO)
+        # ZLNG_HIP_SO: another build of the same sources (scripts/sanitize.sh device: kernels under -fsanitize=address)
+        L = C.CDLL(os.environ.get("ZLNG_HIP_SO") or HIP_SO)
         L.zlng_device_count.restype = C.c_int
         L.zlng_create.restype = C.c_void_p
         L.zlng_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_wave(ParseArgs a) {
             // round state is wave-uniform by construction; pin it to scalar registers
             q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
             // a round adds at most one token per window position; out of token words -> the host grows the pool and repeats
-            if (nt + 64u > a.tok_cap) { overflow = true; break; }
+            if (a.tok_cap < kTokCapMax && nt + 64u > a.tok_cap) { overflow = true; break; }
             const int P = q;
             if (lane == 0) __atomic_store_n(&pf_pos, P, __ATOMIC_RELAXED);
             unsigned long long t0 = 0, t1 = 0, t2 = 0;

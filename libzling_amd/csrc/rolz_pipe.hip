@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void k_rolz_parse_pipe(ParseArgs a) {
 
         while (q < ilen && opos + 1 < kSubSyms) {    // ---- one round = the rest of one grid window
             q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
-            if (nt + 64u > a.tok_cap) { overflow = true; break; }
+            if (a.tok_cap < kTokCapMax && nt + 64u > a.tok_cap) { overflow = true; break; }
             const int j = q >> 6;
             const int P = j << 6;
             const int pos = P + lane;

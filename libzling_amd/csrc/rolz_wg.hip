@@ -259,7 +259,8 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
 
         while (q < ilen && opos + 1 < kSubSyms) {
             q = (int)ufl((uint32_t)q); opos = (int)ufl((uint32_t)opos); nt = ufl(nt); prevty = ufl(prevty);
-            if (nt + 64u > a.tok_cap) { overflow = true; break; }
+            // (a pool of one word per input byte cannot run out: no check, no false alarm on a block of one-byte tokens)
+            if (a.tok_cap < kTokCapMax && nt + 64u > a.tok_cap) { overflow = true; break; }
 
             if (serial_next) {
                 // ---------------- exact serial token at q (a hard lane): the pending boundary event, then MatchAndUpdate /

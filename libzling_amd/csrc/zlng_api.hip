@@ -378,6 +378,8 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
     const uint32_t G = rank_group_blocks(c, nb);
     if (c->tokens_ranked) do_parse = true;            // a failed finish ranked the pending tokens in place: parse again
     CTX_HIP(hipMemcpyAsync(c->d_mtf_snap, c->d_mtf, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+    // from here on a failed call puts the tables back (zlng.h: a failed call leaves the stream state as it found it)
+#define ENC_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->last_hip_error = e_; return fail_restore(c, ZLNG_E_DEVICE); } } while (0)
 
     c->last_passes = 0;
     for (bool grown = false;; grown = true) {         // second turn only after a token-pool overflow
@@ -386,28 +388,28 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
             // speculation: the requested level everywhere, except that a range entered at level 0 (the previous range ended
             // incompressible) is assumed to stay there
             for (size_t k = 0; k < nsubs; k++) c->h_sched[k] = (uint8_t)(entry_level != c->level ? entry_level : c->level);
-            CTX_HIP(hipMemsetAsync(overflow_flag(c), 0, 8, c->stream));
+            ENC_HIP(hipMemsetAsync(overflow_flag(c), 0, 8, c->stream));
         }
         int final_level = entry_level;
         uint32_t restart = 0;                          // first block to (re)parse; a multiple of G
         bool parse_now = do_parse, overflow = false;
         for (int attempt = 0;; attempt++) {
             if (parse_now) {
-                CTX_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
+                ENC_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
                 run_front(c, d_in, in_len, nb, restart);
                 c->last_passes++;
             }
             if (attempt > 0)
-                CTX_HIP(hipMemcpyAsync(c->d_mtf, c->d_mtf_snap + (size_t)(restart / G) * ZLNG_MTF_STATE, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
+                ENC_HIP(hipMemcpyAsync(c->d_mtf, c->d_mtf_snap + (size_t)(restart / G) * ZLNG_MTF_STATE, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream));
             c->tokens_ranked = true;
             int rc = run_back(c, nb, restart / G, d_out, out_cap);
             if (rc != ZLNG_OK) return fail_restore(c, rc);
             if (c->level == 0) { final_level = 0; break; }        // level 0: adaptation is inert
             uint32_t of = 0;
-            CTX_HIP(hipMemcpyAsync(&of, overflow_flag(c), 4, hipMemcpyDeviceToHost, c->stream));
-            CTX_HIP(hipMemcpyAsync(c->h_nsub.data(), c->d_nsub, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            CTX_HIP(hipMemcpyAsync(c->h_cuts.data(), c->d_cuts, nsubs * sizeof(SubCut), hipMemcpyDeviceToHost, c->stream));
-            CTX_HIP(hipMemcpyAsync(c->h_olen.data(), c->d_olen, nsubs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            ENC_HIP(hipMemcpyAsync(&of, overflow_flag(c), 4, hipMemcpyDeviceToHost, c->stream));
+            ENC_HIP(hipMemcpyAsync(c->h_nsub.data(), c->d_nsub, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            ENC_HIP(hipMemcpyAsync(c->h_cuts.data(), c->d_cuts, nsubs * sizeof(SubCut), hipMemcpyDeviceToHost, c->stream));
+            ENC_HIP(hipMemcpyAsync(c->h_olen.data(), c->d_olen, nsubs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             if (hipStreamSynchronize(c->stream) != hipSuccess) return fail_restore(c, ZLNG_E_DEVICE);
             if (of) { overflow = true; break; }
             uint32_t bad = 0;
@@ -435,7 +437,7 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
             hipMemcpyAsync(c->d_mtf, c->d_mtf_snap, ZLNG_MTF_STATE, hipMemcpyDeviceToDevice, c->stream);
             hipStreamSynchronize(c->stream);
             const int rc = alloc_token_pools(c, kTokCapMax);
-            if (rc != ZLNG_OK) return rc;
+            if (rc != ZLNG_OK) { c->tokens_ranked = false; c->pending_in = nullptr; return rc; }   // (tables restored above; the pools are gone: nothing stays pending)
             do_parse = true;
             continue;
         }
@@ -449,6 +451,7 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
         return ZLNG_OK;
     }
 }
+#undef ENC_HIP
 
 }  // namespace
 
@@ -599,6 +602,7 @@ int zlng_encode_parse_device(zlng_ctx* c, const void* d_in, size_t in_len) {
     if (!c || !c->is_encode || !d_in || in_len == 0) return ZLNG_E_ARG;
     const uint32_t nb = blocks_of(in_len);
     if (nb > c->max_blocks) return ZLNG_E_ARG;
+    if (!c->d_tok || !c->d_lit_byte || !c->d_snap || !c->d_nfr) return ZLNG_E_NOMEM;      // an earlier pool growth ran out of HBM
     CTX_HIP(hipSetDevice(c->device));
     const size_t nsubs = (size_t)nb * kMaxSub;
     timer_begin(c);
@@ -637,6 +641,10 @@ int zlng_encode_finish(zlng_ctx* c, uint8_t* out, size_t out_cap, size_t* out_le
     if (!c || !c->pending_in || !out || !out_len) return ZLNG_E_ARG;
     *out_len = 0;
     size_t produced = 0;
+    {   // the pending range may have come from zlng_encode_parse_device: the staging buffer is sized here, not assumed
+        const int rc0 = ensure_out(c, zlng_encode_bound(c->pending_len));
+        if (rc0 != ZLNG_OK) return rc0;
+    }
     const int rc = zlng_encode_finish_device(c, c->d_out, std::min(zlng_encode_bound(c->pending_len), out_cap), &produced, per_block_out_end);
     if (rc != ZLNG_OK) return rc;
     CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));

@@ -267,11 +267,16 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
         handler->OnInit();
     }
     {
-        const int nb = std::min(batch_blocks(), 64);
+        const int nb_full = std::min(batch_blocks(), 64);
+        // Small streams are the common case for a library call: start with a 4-block context (the decode pools cost ~80 MB
+        // of HBM per block) and an uninitialised buffer, and move to the full batch once the stream has filled the small one.
+        int nb = std::min(nb_full, 4);
         CtxGuard ctx(make_ctx(0, false, nb));
         // A .zlng stream has no index: the compressed bytes are pulled in chunks, whole blocks found in
         // the accumulated prefix are decoded, the unconsumed tail is kept for the next round.
-        std::vector<unsigned char> z, raw((size_t)nb * kBlock);
+        std::vector<unsigned char> z;
+        RawBuf raw;
+        raw.resize((size_t)nb * kBlock);
         std::vector<size_t> ends((size_t)nb);
         const size_t chunk = 8u << 20;
         size_t zoff = 0;                                  // consumed prefix of z (compacted now and then, not per round)
@@ -310,6 +315,18 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
                 prev = ends[b];
             }
             zoff += used;
+            if (nb < nb_full && produced == (size_t)nb * kBlock) {       // a full small batch: the stream is long, take the full-size context
+                std::vector<unsigned char> st(ZLNG_MTF_STATE);
+                int lv = 0;
+                if (zlng_get_state(ctx.c, st.data(), &lv) != ZLNG_OK) throw std::runtime_error(zlng_strerror(ZLNG_E_DEVICE));
+                zlng_destroy(ctx.c);
+                ctx.c = nullptr;
+                nb = nb_full;
+                ctx.c = make_ctx(0, false, nb);
+                if (zlng_set_state(ctx.c, st.data(), 0) != ZLNG_OK) throw std::runtime_error(zlng_strerror(ZLNG_E_DEVICE));
+                raw.resize((size_t)nb * kBlock);
+                ends.assign((size_t)nb, 0);
+            }
             if (used == 0 && eof) {
                 if (z.size() != zoff) throw std::runtime_error(zlng_strerror(ZLNG_E_TRUNC));
                 break;

@@ -100,3 +100,24 @@ void zt_generate(uint8_t* out, size_t n, uint64_t first_chunk) {
         zt_generate_chunk(out + off, len, first_chunk + (uint64_t)b);
     }
 }
+
+/* de Bruijn sequence B(256, 3) (Fredricksen-Kessler-Maiorana): 16,777,216 bytes in which every 3-byte window occurs once.
+ * XOR 0x55 it is a block the reference parses into one token per byte -- the worst case of the token pools (tests). */
+static uint8_t* g_db_out;
+static size_t   g_db_n;
+static int      g_db_a[4];
+static void zt_db(int t, int p) {
+    if (t > 3) {
+        if (3 % p == 0) for (int i = 1; i <= p; i++) g_db_out[g_db_n++] = (uint8_t)g_db_a[i];
+        return;
+    }
+    g_db_a[t] = g_db_a[t - p];
+    zt_db(t + 1, p);
+    for (int j = g_db_a[t - p] + 1; j < 256; j++) { g_db_a[t] = j; zt_db(t + 1, t); }
+}
+size_t zt_debruijn3(uint8_t* out) {
+    g_db_out = out; g_db_n = 0;
+    g_db_a[0] = g_db_a[1] = g_db_a[2] = g_db_a[3] = 0;
+    zt_db(1, 1);
+    return g_db_n;
+}

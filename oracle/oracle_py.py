@@ -14,6 +14,8 @@ _u8p = C.POINTER(C.c_uint8)
 
 
 def build(force=False):
+    if os.environ.get("ZLNG_ORACLE_SO"):             # scripts/sanitize.sh: the ASan/UBSan build of the same source
+        return os.environ["ZLNG_ORACLE_SO"]
     so = os.path.join(HERE, "liboracle.so")
     src = os.path.join(HERE, "zlng_oracle.c")
     stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
@@ -138,6 +140,8 @@ class Reference:
 
     @staticmethod
     def available():
+        if os.environ.get("ZLNG_NO_REF") == "1":       # scripts/sanitize.sh: the uninstrumented reference stays out of an ASan process
+            return False
         build()
         return os.path.exists(os.path.join(HERE, "_ref", "libzling_ref.so"))
 
@@ -214,4 +218,15 @@ def textgen(n, first_chunk=0):
     out = np.empty(n, dtype=np.uint8)
     if n:
         _tg.zt_generate(_ptr(out), n, first_chunk)
+    return out
+
+
+def debruijn3():
+    """de Bruijn sequence B(256, 3): 16,777,216 bytes, every 3-byte window once (libzling_amd/host/textgen.c)."""
+    textgen(0)
+    _tg.zt_debruijn3.argtypes = [_u8p]
+    _tg.zt_debruijn3.restype = C.c_size_t
+    out = np.empty(1 << 24, dtype=np.uint8)
+    n = _tg.zt_debruijn3(_ptr(out))
+    assert n == 1 << 24
     return out

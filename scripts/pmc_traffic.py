@@ -9,7 +9,7 @@ import glob, hashlib, json, os, re, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-ENCODE_KERNEL_SOURCES = ("zlng_common.h", "zlng_kernels.h", "rolz_dev.h", "rolz_parse.hip", "mtf_rank.hip", "huffman.hip")
+ENCODE_KERNEL_SOURCES = ("zlng_common.h", "zlng_kernels.h", "rolz_dev.h", "rolz_wg.hip", "mtf_rank.hip", "huffman.hip")
 
 
 def kernel_source_sha():
@@ -27,7 +27,7 @@ def per_kernel(path, counter):
     q = "select kernel_name, dispatch_id, sum(value), max(duration) from counters_collection where counter_name = ? group by dispatch_id"
     for name, _, val, dur in db.execute(q, (counter,)):
         short = re.sub(r"\(.*$", "", name).replace("void ", "").replace("zlng::", "")
-        short = re.sub(r"^(k_rolz_parse_wave)<.*>$", r"\1", short)
+        short = re.sub(r"^(k_rolz_parse_wave|k_rolz_parse_wg)<.*>$", r"\1", short)
         o = out.setdefault(short, {"n": 0, "v": 0.0, "ns": 0.0})
         o["n"] += 1; o["v"] += val; o["ns"] += dur
     return {k: (o["v"] / o["n"], o["ns"] / o["n"] / 1e6) for k, o in out.items()}

@@ -38,9 +38,29 @@ def walk(z):
     return out
 
 
+def config4_share():
+    """BASELINE config 4's per-GPU share through the reference: SHA-256 and size of the e4 .zlng of the first 8 GiB of the
+    synthetic stream (needs ~11 GB of memory and a couple of minutes); updates manifest.json in place."""
+    import hashlib
+    from oracle_py import textgen
+    n = 8 << 30
+    x = textgen(n, 0)
+    z = Reference().encode(x, 4)
+    man = json.load(open(os.path.join(HERE, "manifest.json")))
+    man["config4_share"].update({"bytes": n, "level": 4, "zlng_bytes": int(z.size), "sha256": hashlib.sha256(z.tobytes()).hexdigest()})
+    json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+    print("config4_share:", man["config4_share"]["zlng_bytes"], man["config4_share"]["sha256"])
+
+
 def main():
+    if "--config4" in sys.argv:
+        return config4_share()
     ref = Reference()
     man = {"inputs": {}, "streams": {}, "rolz": {}}
+    try:
+        man["config4_share"] = json.load(open(os.path.join(HERE, "manifest.json")))["config4_share"]      # expensive: kept unless --config4
+    except Exception:
+        pass
     for name in corpus.ALL:
         x = corpus.get(name)
         man["inputs"][name] = {"size": int(x.size), "sha256": corpus.sha(x)}

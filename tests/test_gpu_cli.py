@@ -10,7 +10,7 @@ import corpus
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEMO = os.path.join(ROOT, "tools", "zling_demo")
+DEMO = os.environ.get("ZLNG_DEMO") or os.path.join(ROOT, "tools", "zling_demo")      # ZLNG_DEMO: scripts/sanitize.sh host (the ASan build)
 G = os.path.join(ROOT, "tests", "golden")
 
 

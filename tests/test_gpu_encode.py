@@ -379,3 +379,20 @@ def test_long_matches_across_a_block_end(zl, oracle, level):
         z = zl.encode(data, level)
         ref = oracle.encode(data, level)
         assert z.size == ref.size and np.array_equal(z, ref)
+
+
+def test_a_block_of_one_byte_tokens_fills_the_largest_token_pool_exactly(zl, oracle):
+    """de Bruijn B(256, 3) XOR 0x55: a 16 MiB block the reference parses into 16,777,216 tokens, one per input byte -- the worst
+    case of the token pools (kTokCapMax words per block).  The parser's overflow check must not fire on the pool that cannot
+    overflow; the default pool overflows once and the call repeats on the grown pools (2 passes)."""
+    from oracle_py import debruijn3
+    x = debruijn3() ^ np.uint8(0x55)
+    tok, cuts = oracle.parse_block(x, 0)
+    assert tok.size == x.size == 1 << 24
+    with zl.Stream(0, 0, True, 1) as s:
+        z = s.encode(x)
+        assert s.passes() == 2
+        t, _c = s.block_tokens(0)
+        assert t.size == 1 << 24
+    ref = oracle.encode(x, 0)
+    assert z.size == ref.size and np.array_equal(z, ref)

@@ -36,3 +36,50 @@ def test_enwik9_shape_e0_matches_oracle_blockwise(oracle):
         last = enc
         p += 13 + ol
     assert p == z.size and blocks == nb and covered == n
+
+
+def test_config4_share_e4_512_blocks_through_four_contexts(manifest):
+    """BASELINE config 4, one GPU's share: 8 GiB = 512 blocks of the synthetic stream at e4 through sharding.RangeEncoder
+    (4 contexts of 128 blocks, all parsing at once; MTF tables + current_level handed context to context).  The first 512 MiB
+    are compared byte for byte with the real reference when oracle/_ref is present (else the oracle); the whole stream's
+    SHA-256 and size are the reference's own (tests/golden/manifest.json "config4_share": pinned from a full reference run)."""
+    import torch
+    import libzling_amd as zl
+    from libzling_amd import sharding
+    from oracle_py import Oracle, Reference, textgen
+    pin = manifest["config4_share"]
+    n, level = pin["bytes"], pin["level"]
+    x = textgen(n, 0)
+    nb = n // zl.BLOCK
+    d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
+    step = 1 << 30
+    for o in range(0, n, step):
+        d_in[o:o + step].copy_(torch.from_numpy(x[o:o + step]))
+    d_in[n:].zero_()
+    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(0, level, True, blocks), nb, 128)
+    assert len(enc.parts) == 4 and all(p == 128 for p in enc.parts)
+    cap = zl.encode_bound(n) + 4 * len(enc.parts)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_state = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
+    st0, lv0 = enc.streams[0].get_state()
+    d_state[:zl.MTF_STATE].copy_(torch.from_numpy(st0))
+    torch.cuda.synchronize()
+    enc.parse(d_in.data_ptr(), n)
+    segs, _lv = enc.finish(d_out.data_ptr(), cap, d_state.data_ptr(), lv0)
+    torch.cuda.synchronize()
+    assert sum(k for _, k in segs) == pin["zlng_bytes"]
+    h = hashlib.sha256()
+    head = []
+    for o, k in segs:
+        part = d_out[o:o + k].cpu().numpy()
+        h.update(part.tobytes())
+        if sum(p.size for p in head) < (600 << 20):
+            head.append(part)
+    assert h.hexdigest() == pin["sha256"]
+    # a whole-block prefix of the input encodes to a prefix of the stream (state only flows forward)
+    sample = 512 << 20
+    cpu = Reference() if Reference.available() else Oracle()
+    z = cpu.encode(x[:sample], level)
+    got = np.concatenate(head)[: z.size]
+    assert got.size == z.size and np.array_equal(got, z)
+    enc.close()
