@@ -191,7 +191,7 @@ __device__ __forceinline__ bool ev_state(u64 M, u64 COND, uint32_t m0, const uin
 // One workgroup per block.  NW wavefronts; lane g = 64 * wavefront + lane stands for position P + g.  The fixed-point iteration
 // works on the TOKENS of S, numbered by rank (their order in S; at most 64 per round): every relation between tokens -- same hash
 // slot, same bucket, same MRU key -- is one 64-bit rank mask in LDS, rebuilt per iteration by the tokens of S themselves.
-template <int NW, bool kAllL0, bool kProf>
+template <int NW, bool kAllL0, bool kProf, bool kWide>
 __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     constexpr int NL = 64 * NW;
     __shared__ uint16_t heads[256];
@@ -223,7 +223,6 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     const int wv = (int)ufl((uint32_t)(tid >> 6));
     const u64 lane_bit = 1ull << lane;
     const u64 lbelow = lane_bit - 1ull;
-    constexpr bool kWide = kAllL0;                   // slot plane form (zlng_common.h): the launcher's reset matches
 
     for (int i = tid; i < 2 * 257; i += NL) { (&ctxrow[0][0])[i] = 0; (&ekrow[0][0])[i] = 0; }
     for (int i = tid; i < 2 * (kWgRows + 1); i += NL) (&keyrow[0][0])[i] = 0;
@@ -732,15 +731,18 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     }
 }
 
-void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks_all, hipStream_t s, bool all_level0, int nw) {
+void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks_all, hipStream_t s, bool all_level0, int nw, bool wide) {
     const bool prof = a.dbg != nullptr;
     const uint32_t nblocks = nblocks_all - a.blk0;
-#define ZLNG_WG_LAUNCH(NW)                                                                                                   \
-    do {                                                                                                                     \
-        if (all_level0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);   \
-        else if (all_level0) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);        \
-        else if (!prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);           \
-        else hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);                       \
+    // kWide: slot plane form (zlng_common.h; the caller's k_dict_reset matches).  Only a level-0 context can use the wide form.
+#define ZLNG_WG_LAUNCH(NW)                                                                                                          \
+    do {                                                                                                                            \
+        if (all_level0 && wide && !prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, false, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);   \
+        else if (all_level0 && wide) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, true, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);        \
+        else if (all_level0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, false, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);     \
+        else if (all_level0) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, true, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);               \
+        else if (!prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, false, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);                  \
+        else hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, true, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);                              \
     } while (0)
     if (nw <= 2) ZLNG_WG_LAUNCH(2);
     else if (nw <= 4) ZLNG_WG_LAUNCH(4);

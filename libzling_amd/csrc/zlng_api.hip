@@ -207,9 +207,11 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
                  c->tok_cap, blk0, overflow_flag(c), settle_pf, lazy_fix};
     static const int wg_waves = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
-    launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, c->parser_kind >= 2 && c->level == 0);
+    static const bool wg_wide = !(getenv("ZLNG_WG_COMPACT") && atoi(getenv("ZLNG_WG_COMPACT")) != 0);   // slot plane of the wg parser at level 0 (A/B switch)
+    const bool wide = c->level == 0 && (c->parser_kind == 2 || (c->parser_kind == 3 && wg_wide));
+    launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, wide);
     timer_mark(c, "dict_reset");
-    if (c->parser_kind == 3) { pa.pf_waves = pf_env > 0 ? 1 : 0; launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves); }
+    if (c->parser_kind == 3) { pa.pf_waves = pf_env > 0 ? 1 : 0; launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves, wide); }
     else if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
     else if (c->parser_kind == 0) { pa.pf_ahead = pipe_lead; pa.pf_waves = pipe_pf; launch_rolz_parse_pipe(pa, nb, c->stream, c->level == 0); }
     else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
