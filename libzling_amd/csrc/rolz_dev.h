@@ -211,6 +211,9 @@ struct Spec {
     bool open;
     uint32_t ov0;                        // node 0's slot word (the inserting lane stores it as its link's copy)
     uint32_t lkey1;                      // exact key of the lazy probe at +1: context << 13 | hash13 (speculate_l0w)
+    // generic levels, for the workgroup parser's in-window evaluation: best (len | node << 9) over the first depth-1 / depth-2
+    // nodes of the chain, and the index of the first node of each probe's chain that vetoes (its depth if none)
+    uint32_t pre1, pre2, vpos1, vpos2;
 };
 
 __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
@@ -243,7 +246,7 @@ __device__ __forceinline__ uint32_t lcp_tail(const uint8_t* a, const uint8_t* b,
 // wave-uniformly (`while any lane is still walking`) with per-lane predicates instead of per-lane breaks: a divergent
 // break costs a handful of exec-mask instructions per lane group, a uniform loop costs one scalar branch.
 __device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, int ppos, uint32_t lctx, uint32_t first, uint32_t lov,
-                                            uint32_t lsfx, uint32_t m, int depth, uint32_t lhead, bool active, bool& veto, uint32_t& ld) {
+                                            uint32_t lsfx, uint32_t m, int depth, uint32_t lhead, bool active, bool& veto, uint32_t& ld, uint32_t& vpos) {
     // (n, lov = offset[n], lsfx = suffix[n]) travel together, so a chain hop is ONE round trip: the source word
     // of node n and both ring fields of its successor are requested at the same time
     Bucket B(dict, lctx);
@@ -257,7 +260,7 @@ __device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, i
         const uint32_t nn = lsfx;
         const uint32_t nov = B.offset[nn & (kRing - 1)];
         const uint32_t nsfx = B.suffix[nn & (kRing - 1)];
-        if (active && probe == srcw) { veto = true; active = false; }
+        if (active && probe == srcw) { veto = true; vpos = (uint32_t)i; active = false; }
         active = active && nn != 65535u;
         if (active) ld = min(ld, ring_dist(nn, lhead));
         active = active && !(off <= (nov & 0xFFFFFF));
@@ -296,7 +299,10 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     Quad qb = ld128u(buf + (cmp ? off : (uint32_t)pos));
     uint32_t nov = B.offset[nx & (kRing - 1)];
     uint32_t nnx = B.suffix[nx & (kRing - 1)];
+    uint32_t pre1 = 0xFFFFFFFFu, pre2 = 0xFFFFFFFFu;                       // (unset: the walk ended before that many nodes)
     for (int i = 0; i < cfg.depth && __any(active); i++) {                 // src/libzling_lz.cpp:240-267
+        if (i == cfg.depth - 1) pre1 = maxlen | maxnode << kSpNodeShift;       // the first i nodes are in
+        if (i == cfg.depth - 2) pre2 = maxlen | maxnode << kSpNodeShift;
         if (active) dmin = min(dmin, ring_dist(node, head0));
         const uint32_t off_n = nov & 0xFFFFFF;
         const bool more = active && nx != 65535u && !(off <= off_n);
@@ -315,12 +321,16 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
         off = off_n; cmp = active && cmp_n; qb = qb_n; nov = nov_n; nnx = nnx_n;
     }
     uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
+    S.pre1 = pre1 == 0xFFFFFFFFu ? (maxlen | maxnode << kSpNodeShift) : pre1;
+    S.pre2 = pre2 == 0xFFFFFFFFu ? (maxlen | maxnode << kSpNodeShift) : pre2;
     const bool lz = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
     const uint32_t m = lz ? maxlen - 3u : 0u;
     bool v1 = false, v2 = false;
     uint32_t ld1 = kRing - 1, ld2 = kRing - 1;
-    if (want1) lazy_spec_u(dict, buf, pos + 1, lctx1, ln1, lov1, lsf1, m, cfg.lazy1, lhead1, lz, v1, ld1);
-    if (want2) lazy_spec_u(dict, buf, pos + 2, lctx2, ln2, lov2, lsf2, m, cfg.lazy2, lhead2, lz, v2, ld2);
+    uint32_t vp1 = (uint32_t)cfg.lazy1, vp2 = (uint32_t)cfg.lazy2;
+    if (want1) lazy_spec_u(dict, buf, pos + 1, lctx1, ln1, lov1, lsf1, m, cfg.lazy1, lhead1, lz, v1, ld1, vp1);
+    if (want2) lazy_spec_u(dict, buf, pos + 2, lctx2, ln2, lov2, lsf2, m, cfg.lazy2, lhead2, lz, v2, ld2, vp2);
+    S.vpos1 = vp1; S.vpos2 = vp2;
     if (v1) sp |= kSpVeto1;
     if (v2) sp |= kSpVeto2;
     if (ld1 < risk_dist) sp |= kSpRisk1;

@@ -58,6 +58,8 @@ struct WSpec {
     uint32_t lkey1, lkey2;       // exact keys of the probes: context << 13 | hash13
     uint32_t ld1, ld2;           // ring distance ahead of the PROBE bucket's head of the nearest node a probe visited (4095 = none)
     uint32_t lsrc1;              // level 0: source offset of the probe's chain head | exists << 31
+    uint32_t pre1, pre2;         // levels 1-4: best (len | node << 9) over the first depth-1 / depth-2 chain nodes
+    uint32_t vpos1, vpos2;       // levels 1-4: index of the first node of a probe's chain that vetoes (its depth if none)
 };
 
 // Level 0 (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130), straight-line predicated code: three dependent round
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 Spec S1;
                 S1.sp = kMatchMin - 1; S1.node0 = 65535; S1.head0 = 0; S1.dmin = kRing - 1;
                 S1.lkix1 = S1.lkix2 = S1.lctx1 = S1.lctx2 = 0; S1.lz1 = S1.lz2 = false; S1.ld1 = S1.ld2 = kRing - 1; S1.ov0 = 0;
+                S1.pre1 = S1.pre2 = kMatchMin - 1; S1.vpos1 = S1.vpos2 = 0;
                 if (canm) speculate(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk);
                 W.len = S1.sp & kSpLenMask; W.node = (S1.sp >> kSpNodeShift) & (kRing - 1);
                 W.node0 = S1.node0; W.ov0 = S1.ov0; W.dmin = S1.dmin; W.d0 = W.d1 = S1.dmin;
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 W.lkey1 = lctx1 << 13 | (hash_of(w4 >> 8 | qtext.b << 24) % kHashSlots);
                 W.lkey2 = lctx2 << 13 | (hash_of(w4 >> 16 | qtext.b << 16) % kHashSlots);
                 W.ld1 = S1.ld1; W.ld2 = S1.ld2; W.lsrc1 = 0;
+                W.pre1 = S1.pre1; W.pre2 = S1.pre2; W.vpos1 = S1.vpos1; W.vpos2 = S1.vpos2;
             }
             const uint32_t head0 = heads[ctx];
             const uint32_t m0c = mru[ctx], m0e = mru[ek];           // MRU slots of my check key / my event key at the start of the round
@@ -569,24 +573,76 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     }
                     is_match = is_match && !(lzq && !lconf && veto);
                 } else {
-                    // levels 1-4: a token of this round in my hash slot, a rewritten ring slot or a touched lazy read set -> hard
-                    const bool kq = (KM & rbelow) != 0ull;
-                    hard = ecan && (kq || W.dmin <= k);
+                    // levels 1-4 (depth 4..16, probes of depth up to 4 and 2).  One or two tokens of this round in my hash slot head my
+                    // chain; behind them come the first depth - j nodes of the chain the speculation walked, whose best it recorded
+                    // (pre1 / pre2).  Three or more, a rewritten ring slot, a probe whose length changed -> hard.
+                    const u64 kq = KM & rbelow;
+                    const bool has_a1 = kq != 0ull;
+                    const int a1 = top_bit(kq | 1ull);
+                    const u64 kq2 = kq & ~(1ull << a1);
+                    const bool has_a2 = has_a1 && kq2 != 0ull;
+                    const int a2 = has_a2 ? top_bit(kq2 | 1ull) : a1;
+                    const bool has_a3 = has_a2 && (kq2 & ~(1ull << a2)) != 0ull;
+                    hard = ecan && (W.dmin <= k || has_a3);
                     ml = W.len; mn = W.node;
+                    const bool fixl = ecan && !hard && has_a1;
+                    if (__any(fixl)) {
+                        const uint32_t k1 = t_key[a1], k2 = t_key[a2], la1 = t_lane[a1], la2 = t_lane[a2];
+                        const Quad q1 = t_q[a1], q2 = t_q[a2];
+                        const bool c1 = fixl && (k1 >> 21) == chk, c2 = fixl && has_a2 && (k2 >> 21) == chk;
+                        uint32_t l1 = c1 ? lcp16(qtext, q1) : 0u, l2 = c2 ? lcp16(qtext, q2) : 0u;
+                        const bool g1 = c1 && l1 == 16u, g2 = c2 && l2 == 16u;
+                        if (__any(g1 || g2)) {
+                            uint32_t x1, x2;
+                            lcp_tail2(buf + upos, buf + (uint32_t)(P + (int)la1), buf + (uint32_t)(P + (int)la2), g1, g2, x1, x2);
+                            l1 = g1 ? x1 : l1; l2 = g2 ? x2 : l2;
+                        }
+                        uint32_t fl = kMatchMin - 1, fn = 0;
+                        if (l1 > fl) { fl = l1; fn = 0x10000u | (uint32_t)a1; }
+                        if (has_a2 && fl != (uint32_t)kMatchMax && l2 > fl) { fl = l2; fn = 0x10000u | (uint32_t)a2; }
+                        const uint32_t pre = has_a2 ? W.pre2 : W.pre1;
+                        if (fl != (uint32_t)kMatchMax && (pre & kSpLenMask) > fl) { fl = pre & kSpLenMask; fn = (pre >> kSpNodeShift) & (kRing - 1); }
+                        if (fixl) { ml = fl; mn = fn; lk = a1; lkchk = k1 >> 21; lklane = la1; }
+                    }
                     is_match = ecan && !hard && ml >= (uint32_t)kMatchMin;
                     const bool lzq = is_match && ml < (uint32_t)kLazyLimit;
-                    const bool c1 = want1 && ((LK1 & rbeq) != 0ull || (uint32_t)__popcll(LC1 & rbeq) > W.ld1);
-                    bool c2 = false;
+                    // a probe: 0 no veto, 1 veto, 2 hard.  [the newest one or two tokens up to me with the probe's key] ++ the first
+                    // depth - h nodes of the chain the speculation walked (vpos), valid while the length is the speculation's.
+                    auto probe = [&](const u64 LK, const u64 LC, uint32_t ld, bool sveto, uint32_t vpos, int Lp, uint32_t pofs) -> uint32_t {
+                        const u64 hm = LK & rbeq;
+                        const bool lconf = (uint32_t)__popcll(LC & rbeq) > ld;
+                        const bool has_h1 = hm != 0ull;
+                        const int h1 = top_bit(hm | 1ull);
+                        const u64 hm2 = hm & ~(1ull << h1);
+                        const bool has_h2 = has_h1 && hm2 != 0ull;
+                        const int h2 = has_h2 ? top_bit(hm2 | 1ull) : h1;
+                        const bool has_h3 = has_h2 && (hm2 & ~(1ull << h2)) != 0ull;
+                        uint32_t st = sveto ? 1u : 0u;
+                        const bool ex = lzq && has_h1 && !lconf && !has_h3 && ml == W.len;
+                        if (lzq && (lconf || (has_h1 && !ex) || ml != W.len)) st = 2u;      // (a changed length would need the probe's chain walked again)
+                        if (__any(ex)) {
+                            const uint32_t mm = ex ? ml - 3u : 0u;
+                            const uint32_t pr = ld32u(buf + (upos + pofs + mm));
+                            const uint32_t s1w = ld32u(buf + ((uint32_t)(P + (int)t_lane[h1]) + mm)), s2w = ld32u(buf + ((uint32_t)(P + (int)t_lane[h2]) + mm));
+                            const uint32_t hcnt = has_h2 ? 2u : 1u;
+                            bool v = pr == s1w || (has_h2 && Lp >= 2 && pr == s2w);
+                            if (!v && hcnt < (uint32_t)Lp) v = vpos < (uint32_t)Lp - hcnt;
+                            if (ex) st = v ? 1u : 0u;
+                        }
+                        return st;
+                    };
+                    const u64 LC1b = LC1;
+                    const uint32_t st1 = want1 ? probe(LK1, LC1b, W.ld1, W.veto1, W.vpos1, cfg.lazy1, 1u) : 0u;
+                    uint32_t st2 = 0u;
                     if (want2) {
                         const u64 LK2 = keyrow[bufi][r_lk2], LC2 = ctxrow[bufi][lc2_r];
-                        c2 = (LK2 & rbeq) != 0ull || (uint32_t)__popcll(LC2 & rbeq) > W.ld2;
+                        st2 = probe(LK2, LC2, W.ld2, W.veto2, W.vpos2, cfg.lazy2, 2u);
                     }
                     // probe 2 is only looked at when probe 1 does not veto (src/libzling_lz.cpp:276-281)
-                    const bool v1 = want1 && W.veto1;
-                    hard = hard || (lzq && (c1 || (!v1 && want2 && c2)));
-                    is_match = is_match && !(lzq && (v1 || (want2 && W.veto2)));
+                    const uint32_t stl = st1 != 0u ? st1 : st2;
+                    hard = hard || (lzq && stl == 2u);
+                    is_match = is_match && !(lzq && stl == 1u);
                 }
-                ZLNG_MK(5);
                 // word MRU of my context after every boundary event of S up to and including mine (src/libzling_lz.cpp:172-185)
                 uint32_t s0 = m0c & 0xFFFF, s1 = m0c >> 16;
                 {

@@ -39,6 +39,8 @@ typedef struct {
     uint32_t ov0;
     uint32_t lkey[2]; int lctx[2], lrisk[2], lwant[2], ld[2];
     int d0, d1, has1;
+    int pl[3], pn[3];      /* generic levels: best (len, node) over the first depth-1 / depth-2 chain nodes ([1], [2]; [0] = all) */
+    int vpos[2], lhit2[2]; /* generic levels: index of the first snapshot node that vetoes probe j (its depth if none) */
     int len0;              /* level 0: candidate length of chain node 0 alone (0 if its check byte differs) */
     int has0;
     int lsrc1_valid; uint32_t lsrc1;   /* level 0: the lazy probe's chain head (snapshot): source offset */
@@ -65,8 +67,14 @@ static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth
     o->node0 = node; o->head0 = head0; o->ov0 = node != 65535 ? b->offset[node] : 0; o->has0 = node != 65535;
     o->len0 = 0; o->d0 = o->d1 = ZO_RING - 1; o->has1 = 0;
     int maxlen = ZO_MATCH_MIN - 1, maxnode = 0;
+    int set1 = 0, set2 = 0;
+    o->pl[1] = o->pl[2] = ZO_MATCH_MIN - 1; o->pn[1] = o->pn[2] = 0;
+    if (depth - 1 <= 0) set1 = 1;
+    if (depth - 2 <= 0) set2 = 1;
     if (node != 65535) {
         for (int i = 0; i < depth; i++) {
+            if (i == depth - 1 && !set1) { o->pl[1] = maxlen; o->pn[1] = maxnode; set1 = 1; }    /* before node i: the first i nodes are in */
+            if (i == depth - 2 && !set2) { o->pl[2] = maxlen; o->pn[2] = maxnode; set2 = 1; }
             int d = ring_dist(node, head0); if (d < dmin) dmin = d;
             if (i == 0) o->d0 = d;
             uint32_t off = b->offset[node] & 0xFFFFFF;
@@ -84,6 +92,9 @@ static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth
             node = nx;
         }
     }
+    if (!set1) { o->pl[1] = maxlen; o->pn[1] = maxnode; }       /* the walk ended before that many nodes */
+    if (!set2) { o->pl[2] = maxlen; o->pn[2] = maxnode; }
+    o->pl[0] = maxlen; o->pn[0] = maxnode;
     o->dmin = dmin; o->sp_len = maxlen; o->sp_node = maxnode;
     int veto = 0;
     const int lz = maxlen >= ZO_MATCH_MIN && maxlen < ZO_LAZY_LIMIT;
@@ -97,12 +108,13 @@ static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth
         o->lctx[j] = buf[pp - 1]; o->lkey[j] = (uint32_t)buf[pp - 1] << 13 | hh;
         int n = lb->hash[hh], ld = ZO_RING - 1;
         if (j == 0) { o->lsrc1_valid = n != 65535; o->lsrc1 = n != 65535 ? (lb->offset[n] & 0xFFFFFF) : 0; }
+        o->vpos[j] = ldepth[j];
         if (n != 65535 && lz) {
             int m = maxlen - 3;
             for (int i = 0; i < ldepth[j]; i++) {
                 int d = ring_dist(n, lb->head); if (d < ld) ld = d;
                 uint32_t off = lb->offset[n] & 0xFFFFFF;
-                if (le32(buf + pp + m) == le32(buf + off + m)) { veto = 1; break; }
+                if (le32(buf + pp + m) == le32(buf + off + m)) { if (!(j == 1 && veto)) {} o->vpos[j] = i; if (j == 0 || !veto) veto = 1; break; }
                 int nx = lb->suffix[n];
                 if (nx == 65535) break;
                 d = ring_dist(nx, lb->head); if (d < ld) ld = d;
@@ -280,6 +292,26 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                                 link = a1;
                                 is_match = mlen >= ZO_MATCH_MIN;
                                 st.fixes++;
+                            } else if (fix && level > 0) {
+                                /* generic depth: chain = [a1, a2] ++ the first depth - j nodes of the snapshot's chain (j <= 2) */
+                                int a3 = -1;
+                                for (int j = a2 - 1; a2 >= 0 && j >= 0; j--) if (S[j] && L[j].canm && L[j].key == l->key) { a3 = j; break; }
+                                if (a3 >= 0 || depth < 3) { l->hard = 1; l->hardcls = 1; }
+                                else {
+                                    const uint8_t* p = ibuf + l->pos;
+                                    const int jn = a2 >= 0 ? 2 : 1;
+                                    mlen = 3; mnode = 0;
+                                    int l1 = L[a1].chk == l->chk ? common_len(p, ibuf + L[a1].pos) : 0;
+                                    if (l1 > mlen) { mlen = l1; mnode = -1 - a1; }
+                                    if (a2 >= 0 && mlen != ZO_MATCH_MAX) {
+                                        int l2 = L[a2].chk == l->chk ? common_len(p, ibuf + L[a2].pos) : 0;
+                                        if (l2 > mlen) { mlen = l2; mnode = -1 - a2; }
+                                    }
+                                    if (mlen != ZO_MATCH_MAX && l->pl[jn] > mlen) { mlen = l->pl[jn]; mnode = l->pn[jn]; }
+                                    link = a1;
+                                    is_match = mlen >= ZO_MATCH_MIN;
+                                    st.fixes++;
+                                }
                             } else { l->hard = 1; l->hardcls = 1; }
                         } else { is_match = l->sp_len >= ZO_MATCH_MIN; mlen = l->sp_len; mnode = l->sp_node; }
                         if (!l->hard && is_match && mlen < ZO_LAZY_LIMIT) {
@@ -295,6 +327,20 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                                     const int m = mlen - 3, pp = l->pos + 1;
                                     if (lhit[j2] >= 0) { veto = le32(ibuf + pp + m) == le32(ibuf + L[lhit[j2]].pos + m); st.lfixes++; }
                                     else veto = l->lsrc1_valid && le32(ibuf + pp + m) == le32(ibuf + l->lsrc1 + m);
+                                } else if (fix && level > 0 && !lconf[j2] && mlen == l->sp_len && lhits[j2] <= 2) {
+                                    /* generic probe: [the newest one or two accepted starts with the probe's key] ++ the first depth - h nodes
+                                     * of the snapshot's probe chain; the length is the speculation's, so the snapshot part is known (vpos) */
+                                    const int Lp = j2 == 0 ? lazy1 : lazy2, m = mlen - 3, pp = l->pos + 1 + j2;
+                                    int h = 0;
+                                    for (int j = g; j >= 0 && h < Lp && !veto; j--) if ((S[j] || j == g) && L[j].canm && L[j].key == l->lkey[j2]) {
+                                        if (le32(ibuf + pp + m) == le32(ibuf + L[j].pos + m)) veto = 1;
+                                        h++;
+                                    }
+                                    if (!veto && h < Lp) {
+                                        /* the speculative walk of probe 2 only ran if probe 1 did not veto: its vpos is valid then (same here) */
+                                        veto = l->vpos[j2] < Lp - h;
+                                    }
+                                    st.lfixes++;
                                 } else { need_hard = 1; break; }
                             }
                             if (need_hard) { l->hard = 1; l->hardcls = 3; }
