@@ -116,6 +116,13 @@ int zlng_set_state(zlng_ctx*, const uint8_t mtf[ZLNG_MTF_STATE], int current_lev
 int zlng_get_state_device(zlng_ctx*, void* d_mtf, int* current_level);
 int zlng_set_state_device(zlng_ctx*, const void* d_mtf, int current_level);
 
+/* MEASURED ALTERNATIVE, off by default (SURVEY 8(e) Option C; the product path is all-device): the k longest rank chains of every
+ * following encode call (k <= 8; 0 = off) are walked by host threads -- their literal runs cross PCIe and come back as ranks --
+ * while the device walks the other chains.  One wavefront walks a chain at ~19 ns per literal, a host core at ~3.4 ns
+ * (src/libzling_lz.cpp:112-117 is a dependent chain either way), and the chain of the hottest context is the term that does not
+ * shard across GPUs.  Same bytes.  ZLNG_HOST_RANK_CONTEXTS=<k> sets it for every context of a process. */
+int zlng_set_host_rank_contexts(zlng_ctx*, int k);
+
 /* ---- one stream over several devices (replaces the same reference call sites as zlng_encode_blocks) ----
  * A group owns one encode context per entry of `devices` (a device may be listed more than once: several contexts per
  * GPU).  One call takes up to members x max_blocks_per_member blocks of ONE stream: contiguous block ranges are copied
@@ -135,6 +142,7 @@ int zlng_group_encode_parse(zlng_group*, const uint8_t* in, size_t in_len);     
 int zlng_group_encode_finish(zlng_group*, uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
 int zlng_group_get_state(zlng_group*, uint8_t mtf[ZLNG_MTF_STATE], int* current_level);
 int zlng_group_set_state(zlng_group*, const uint8_t mtf[ZLNG_MTF_STATE], int current_level);
+int zlng_group_set_host_rank_contexts(zlng_group*, int k);      /* zlng_set_host_rank_contexts on every member */
 
 /* Decode a stream prefix made of whole blocks from HOST memory; *in_used gets the bytes consumed. */
 int zlng_decode_blocks(zlng_ctx*, const uint8_t* in, size_t in_len, size_t* in_used,

@@ -90,6 +90,8 @@ def lib():
         L.zlng_group_encode_finish.argtypes = [C.c_void_p, _u8p, C.c_size_t, _szp, _szp]
         L.zlng_group_get_state.argtypes = [C.c_void_p, _u8p, C.POINTER(C.c_int)]
         L.zlng_group_set_state.argtypes = [C.c_void_p, _u8p, C.c_int]
+        L.zlng_set_host_rank_contexts.argtypes = [C.c_void_p, C.c_int]
+        L.zlng_group_set_host_rank_contexts.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -227,6 +229,12 @@ class Stream:
         if rc != 0:
             raise ZlngError(rc, "zlng_set_state_device")
 
+    def set_host_rank_contexts(self, k):
+        """Measured alternative (zlng.h): the k longest rank chains of the following calls on host threads; 0 = all-device."""
+        rc = lib().zlng_set_host_rank_contexts(self._h, k)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_set_host_rank_contexts")
+
     def debug_fetch(self, what, blk, dtype, count):
         """Test hook (zlng_debug_fetch): internal buffer `what` of block `blk` after the last encode."""
         out = np.empty(count, dtype=dtype)
@@ -313,6 +321,11 @@ class Group:
             raise ZlngError(rc, "zlng_group_encode")
         self.block_ends = list(ends)[:nb]
         return out[: n.value].copy()
+
+    def set_host_rank_contexts(self, k):
+        rc = lib().zlng_group_set_host_rank_contexts(self._h, k)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_group_set_host_rank_contexts")
 
     def get_state(self):
         buf = np.empty(MTF_STATE, np.uint8)

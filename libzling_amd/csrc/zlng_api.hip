@@ -529,12 +529,7 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
         c->h_cuts.resize(nsubs);
         c->h_blk_end.resize(nb);
         const char* hr = getenv("ZLNG_HOST_RANK_CONTEXTS");
-        c->host_rank_contexts = hr ? std::min(8, std::max(0, atoi(hr))) : 0;
-        if (c->host_rank_contexts > 0) {
-            if ((rc = dev_alloc(c, &c->d_skip, 256))) return fail(rc);
-            if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess)
-                return fail(ZLNG_E_DEVICE);
-        }
+        if (hr && (rc = zlng_set_host_rank_contexts(c, atoi(hr))) != ZLNG_OK) return fail(rc);
         const char* pf = getenv("ZLNG_PROFILE");
         if (pf && pf[0] == '1') {
             if ((rc = dev_alloc(c, &c->d_dbg, nb * kDbgSlots))) return fail(rc);
@@ -652,6 +647,21 @@ int zlng_encode_finish(zlng_ctx* c, uint8_t* out, size_t out_cap, size_t* out_le
     CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
     *out_len = produced;
+    return ZLNG_OK;
+}
+
+// The measured alternative of SURVEY 8(e) Option C as a per-context switch (see include/zlng.h): k = 0 switches it off.
+int zlng_set_host_rank_contexts(zlng_ctx* c, int k) {
+    if (!c || !c->is_encode || k < 0) return ZLNG_E_ARG;
+    k = std::min(8, k);
+    CTX_HIP(hipSetDevice(c->device));
+    if (k > 0 && !c->d_skip) {
+        int rc;
+        if ((rc = dev_alloc(c, &c->d_skip, 256))) return rc;
+        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess)
+            return ZLNG_E_DEVICE;
+    }
+    c->host_rank_contexts = k;
     return ZLNG_OK;
 }
 

@@ -62,6 +62,12 @@ void zlng_group_destroy(zlng_group* g) {
     delete g;
 }
 
+int zlng_group_set_host_rank_contexts(zlng_group* g, int k) {
+    if (!g) return ZLNG_E_ARG;
+    for (zlng_ctx* c : g->member) { const int rc = zlng_set_host_rank_contexts(c, k); if (rc != ZLNG_OK) return rc; }
+    return ZLNG_OK;
+}
+
 int zlng_group_members(const zlng_group* g) { return g ? (int)g->member.size() : 0; }
 size_t zlng_group_capacity(const zlng_group* g) { return g ? g->member.size() * (size_t)g->max_blocks * kBlock : 0; }
 

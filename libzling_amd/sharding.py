@@ -61,6 +61,12 @@ class RangeEncoder:
         self.streams = [make_stream(p) for p in self.parts]
         self._lens = []
 
+    def set_host_rank_contexts(self, k):
+        """The measured hybrid of SURVEY 8(e) Option C on every context of the range: the k longest rank chains of each finish are
+        walked by host threads while the device walks the others and the later ranges are still being parsed; 0 = all-device."""
+        for s in self.streams:
+            s.set_host_rank_contexts(k)
+
     def parse(self, d_in, nbytes):
         off = 0
         self._lens = []

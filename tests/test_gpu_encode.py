@@ -396,3 +396,38 @@ def test_a_block_of_one_byte_tokens_fills_the_largest_token_pool_exactly(zl, ora
         assert t.size == 1 << 24
     ref = oracle.encode(x, 0)
     assert z.size == ref.size and np.array_equal(z, ref)
+
+
+@pytest.mark.parametrize("level", [0, 4])
+def test_hybrid_host_rank_chains_through_group_and_range_encoder(zl, oracle, level):
+    """SURVEY 8(e) Option C wired through the multi-context drivers: zlng_group_set_host_rank_contexts on a group of three
+    members and RangeEncoder.set_host_rank_contexts on a range fed through three contexts -- the k longest rank chains of every
+    member's finish on host threads, the other chains on the device.  Bytes equal the oracle's; switching back to all-device
+    on the same objects gives the same bytes again."""
+    import torch
+    from libzling_amd import sharding
+    B = zl.BLOCK
+    x = _mixed(5 * B + 300_000, 55, [(2 * B - 300_000, 700_000)])
+    ref = oracle.encode(x, level)
+    with zl.Group([0, 0, 0], level, 2) as g:
+        g.set_host_rank_contexts(3)
+        st, lv = g.get_state()
+        assert np.array_equal(g.encode(x), ref)
+        g.set_state(st, lv)
+        g.set_host_rank_contexts(0)
+        assert np.array_equal(g.encode(x), ref)
+    n = x.size
+    nb = (n + B - 1) // B
+    d_in = torch.cat([torch.from_numpy(x).cuda(), torch.zeros(512, dtype=torch.uint8, device="cuda")])
+    out = torch.empty(zl.encode_bound(n) + 64, dtype=torch.uint8, device="cuda")
+    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(0, level, True, blocks), nb, 2)
+    assert len(enc.streams) == 3
+    enc.set_host_rank_contexts(4)
+    stt = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
+    init, lv0 = enc.streams[0].get_state()
+    stt[: zl.MTF_STATE].copy_(torch.from_numpy(init)); torch.cuda.synchronize()
+    enc.parse(d_in.data_ptr(), n)
+    segs, _lv = enc.finish(out.data_ptr(), out.numel(), stt.data_ptr(), lv0)
+    z = np.concatenate([out[a:a + k].cpu().numpy() for a, k in segs])
+    assert z.size == ref.size and np.array_equal(z, ref)
+    enc.close()

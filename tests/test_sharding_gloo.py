@@ -43,6 +43,10 @@ class FakeStream:
     def close(self):
         pass
 
+    def set_host_rank_contexts(self, k):
+        # the fake's codec is the oracle either way; what the test pins is that the switch reaches EVERY context of every rank
+        self.host_rank_contexts = k
+
     def parse_device(self, ptr, n):
         assert (n + BLOCK - 1) // BLOCK <= self.max_blocks
         self.pending = (ptr, n)
@@ -82,7 +86,7 @@ def make_input(kind, total):
     return x
 
 
-def _worker(rank, world, port, total, tmp, kind, level, ctx_blocks):
+def _worker(rank, world, port, total, tmp, kind, level, ctx_blocks, hybrid=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -91,6 +95,9 @@ def _worker(rank, world, port, total, tmp, kind, level, ctx_blocks):
     nb = (n + BLOCK - 1) // BLOCK
     enc = sharding.RangeEncoder(lambda blocks: FakeStream(level, blocks), nb, ctx_blocks)
     assert len(enc.streams) == (nb + ctx_blocks - 1) // ctx_blocks
+    if hybrid:
+        enc.set_host_rank_contexts(4)
+        assert all(getattr(s, "host_rank_contexts", 0) == 4 for s in enc.streams)
     out = np.empty(FakeStream(level, 1).o.lib.zo_encode_bound(n) + 64, np.uint8)
     state = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8)           # this rank's state buffer ("device" = host here)
     buf = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8)             # the exchanged buffer
@@ -130,10 +137,11 @@ def _worker(rank, world, port, total, tmp, kind, level, ctx_blocks):
     (3, 3 * BLOCK - 5, "text", 0, 240),
     (2, 2 * BLOCK + 300_000, "mixed", 4, 240),          # rank 0's range ends incompressible: rank 1 must enter at level 0
     (2, 4 * BLOCK + 50_000, "text", 0, 1),              # per-rank batching: 2-3 contexts of one block per rank
+    (2, 4 * BLOCK + 50_001, "text", 0, 1),              # the same with the host-rank-chain switch set on every context (odd size = hybrid)
 ])
 def test_block_range_sharding_equals_single_stream(tmp_path, world, total, kind, level, ctx_blocks):
-    port = 29500 + (os.getpid() % 2000) + world + 7 * level + ctx_blocks % 5
-    mp.spawn(_worker, args=(world, port, total, str(tmp_path), kind, level, ctx_blocks), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + world + 7 * level + ctx_blocks % 5 + total % 3
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path), kind, level, ctx_blocks, total % 2 == 1 and ctx_blocks == 1), nprocs=world, join=True)
     from oracle_py import Oracle
     whole = Oracle().encode(make_input(kind, total), level)
     parts = np.concatenate([np.fromfile(os.path.join(str(tmp_path), "part%d.zlng" % r), dtype=np.uint8) for r in range(world)])
