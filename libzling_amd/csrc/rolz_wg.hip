@@ -65,23 +65,38 @@ struct WSpec {
 // Level 0 (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130), straight-line predicated code: three dependent round
 // trips after the window's text with the wide slot plane (rolz_dev.h speculate_l0w explains the link copy), then -- only if some
 // lane's compare ran to 16 bytes -- the tails (32 bytes per trip, both nodes in one loop) and the lazy probes of those lanes.
-template <bool kWide>
+// kHot: the bucket of ONE context (`hotctx`, the block's most frequent byte) is mirrored in LDS (`hot`: the wide layout of
+// zlng_common.h, 57,344 B, written through by every insert); lanes of that context -- 40 % of a text's positions -- take their hash
+// head, ring slot and link from LDS, and their global loads are pointed at one shared line instead of 64 scattered ones.
+template <bool kWide, bool kHot>
 __device__ __forceinline__ void speculate_l0t(WSpec& W, Quad& ql_out, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t pos,
-                                              const Quad qa, uint32_t t16, uint32_t ctx, uint32_t hc, uint32_t chk) {
+                                              const Quad qa, uint32_t t16, uint32_t ctx, uint32_t hc, uint32_t chk,
+                                              const uint8_t* hot, uint32_t hotctx) {
     const uint32_t w4 = qa.a;
     const uint32_t lctx1 = w4 & 0xFF;
     const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
     BucketT<kWide> B(dict, ctx), B1(dict, lctx1);
+    const bool h0 = kHot && ctx == hotctx, h1 = kHot && lctx1 == hotctx;
+    const uint16_t* hot_hash = reinterpret_cast<const uint16_t*>(hot + 8u * kRing + 2u * kRing);
+    const uint16_t* hot_sfx = reinterpret_cast<const uint16_t*>(hot + 8u * kRing);
+    const u64* hot_slot = reinterpret_cast<const u64*>(hot);
     // round trip 1: both hash heads
-    const uint32_t node0 = B.hash[hc];
-    const uint32_t ln1 = B1.hash[hh1];
+    uint32_t node0 = B.hash[h0 ? 0u : hc];
+    uint32_t ln1 = B1.hash[h1 ? 0u : hh1];
+    if (kHot) { const uint32_t a0 = hot_hash[h0 ? hc : 0u], a1 = hot_hash[h1 ? hh1 : 0u]; node0 = h0 ? a0 : node0; ln1 = h1 ? a1 : ln1; }
     const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
     // round trip 2: node 0's slot (wide: own word + its link's), its link, the probe node's word
     uint32_t ov0, nov = 0;
-    if (kWide) { const u64 sl0 = B.slot[node0 & (kRing - 1)]; ov0 = (uint32_t)sl0; nov = (uint32_t)(sl0 >> 32); }
+    if (kWide) { const u64 sl0 = B.slot[h0 ? 0u : (node0 & (kRing - 1))]; ov0 = (uint32_t)sl0; nov = (uint32_t)(sl0 >> 32); }
     else ov0 = B.offset[node0 & (kRing - 1)];
-    const uint32_t nx = B.suffix[node0 & (kRing - 1)];
-    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)];
+    uint32_t nx = B.suffix[h0 ? 0u : (node0 & (kRing - 1))];
+    uint32_t lov1 = B1.offset[h1 ? 0u : (ln1 & (kRing - 1))];
+    if (kHot) {
+        const u64 s0 = hot_slot[h0 ? (node0 & (kRing - 1)) : 0u], s1 = hot_slot[h1 ? (ln1 & (kRing - 1)) : 0u];
+        const uint32_t x0 = hot_sfx[h0 ? (node0 & (kRing - 1)) : 0u];
+        if (h0) { ov0 = (uint32_t)s0; nov = (uint32_t)(s0 >> 32); nx = x0; }
+        if (h1) lov1 = (uint32_t)s1;
+    }
     const uint32_t off0 = ov0 & 0xFFFFFF;
     const bool has1s = has0 && nx != 65535u;
     const bool cmp0 = has0 && (ov0 >> 24) == chk;
@@ -193,9 +208,12 @@ __device__ __forceinline__ bool ev_state(u64 M, u64 COND, uint32_t m0, const uin
 // One workgroup per block.  NW wavefronts; lane g = 64 * wavefront + lane stands for position P + g.  The fixed-point iteration
 // works on the TOKENS of S, numbered by rank (their order in S; at most 64 per round): every relation between tokens -- same hash
 // slot, same bucket, same MRU key -- is one 64-bit rank mask in LDS, rebuilt per iteration by the tokens of S themselves.
-template <int NW, bool kAllL0, bool kProf, bool kWide>
+template <int NW, bool kAllL0, bool kProf, bool kWide, bool kHot = false>
 __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     constexpr int NL = 64 * NW;
+    static_assert(!kHot || (kWide && kAllL0), "the LDS bucket mirrors the wide layout of a level-0 context");
+    __shared__ u64 hot_lds[kHot ? kBktBytes / 8 : 1];     // kHot: write-through mirror of one bucket (57,344 B)
+    __shared__ uint32_t hot_hist[kHot ? 256 : 1];
     __shared__ uint16_t heads[256];
     __shared__ uint32_t mru[256];                    // slot0 | slot1 << 16
     __shared__ uint32_t ht_key[kWgRows];             // exact key of a row of keyrow (open addressing; kWgEmpty = free)
@@ -230,6 +248,20 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     for (int i = tid; i < 2 * (kWgRows + 1); i += NL) (&keyrow[0][0])[i] = 0;
     for (int i = tid; i < kWgRows; i += NL) ht_key[i] = kWgEmpty;
     for (int i = tid; i < 256; i += NL) heads[i] = 0;
+    uint32_t hotctx = 256u;                          // (no context)
+    uint8_t* hot = reinterpret_cast<uint8_t*>(hot_lds);
+    if (kHot) {
+        // the block's most frequent byte over its first 64 KiB is the context whose bucket lives in LDS; the mirror starts as Reset() leaves a bucket
+        for (int i = tid; i < 256; i += NL) hot_hist[i] = 0;
+        for (int i = tid; i < (int)(kBktBytes / 8); i += NL) hot_lds[i] = i < (int)kRing ? 0ull : ~0ull;
+        __syncthreads();
+        const int span = ilen < 65536 ? ilen : 65536;
+        for (int i = tid; i < span; i += NL) atomicAdd(&hot_hist[buf[i]], 1u);
+        __syncthreads();
+        uint32_t best = 0, bestc = 0;
+        for (int i = 0; i < 256; i++) { const uint32_t v = hot_hist[i]; if (v > best) { best = v; bestc = (uint32_t)i; } }
+        hotctx = ufl(bestc);
+    }
     __syncthreads();
 
     uint32_t nt = 0;
@@ -286,6 +318,16 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                         mlen = __builtin_amdgcn_readfirstlane(ml);
                         midx = __builtin_amdgcn_readfirstlane(mi);
                         if (lane == 0) heads[cq] = (uint16_t)head;
+                        if (kHot && cq == hotctx && lane == 0) {                     // the same insert into the LDS mirror (MatchAndUpdate, src/libzling_lz.cpp:227-230)
+                            const uint32_t hq = hash_of(ld32u(buf + (uint32_t)q));
+                            const uint32_t hcq = hq % kHashSlots, own = (uint32_t)q | ((hq / kHashSlots) & 255u) << 24;
+                            uint16_t* hh = reinterpret_cast<uint16_t*>(hot + 8u * kRing + 2u * kRing);
+                            const uint32_t node = hh[hcq];
+                            const uint32_t lw = (node == 65535u || node == head) ? own : (uint32_t)hot_lds[node & (kRing - 1)];
+                            reinterpret_cast<uint16_t*>(hot + 8u * kRing)[head] = (uint16_t)node;
+                            hot_lds[head] = (u64)own | (u64)(node == head ? own : (node == 65535u ? 0u : lw)) << 32;
+                            hh[hcq] = (uint16_t)head;
+                        }
                     }
                     uint32_t word, nq = (uint32_t)q, no = (uint32_t)opos, ty;
                     if (is_match) { word = (uint32_t)(258 + mlen - kMatchMin) | (uint32_t)midx << 16; no += 2; nq += (uint32_t)mlen; ty = kTyMatch; }
@@ -333,7 +375,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
             const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
             Quad ql = {0, 0, 0, 0};
             if (level0) {
-                speculate_l0t<kWide>(W, ql, dict, buf, heads[ctx], heads[lctx1], upos, qtext, t16, ctx, hc, chk);
+                speculate_l0t<kWide, kHot>(W, ql, dict, buf, heads[ctx], heads[lctx1], upos, qtext, t16, ctx, hc, chk, hot, hotctx);
             } else {
                 Spec S1;
                 S1.sp = kMatchMin - 1; S1.node0 = 65535; S1.head0 = 0; S1.dmin = kRing - 1;
@@ -733,7 +775,13 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     if (kWide) B.slot[head] = (u64)((uint32_t)pos | chk << 24) | (u64)pword << 32;
                     else B.offset[head] = (uint32_t)pos | chk << 24;
                     // the slot's head must end up being the LAST token of the round in it; the bucket's ring head likewise
-                    if ((KM & Cm & ~(rbelow | rbit)) == 0ull) B.hash[hc] = (uint16_t)head;
+                    const bool hwr = (KM & Cm & ~(rbelow | rbit)) == 0ull;
+                    if (hwr) B.hash[hc] = (uint16_t)head;
+                    if (kHot && ctx == hotctx) {
+                        reinterpret_cast<uint16_t*>(hot + 8u * kRing)[head] = (uint16_t)lslot;
+                        hot_lds[head] = (u64)((uint32_t)pos | chk << 24) | (u64)pword << 32;
+                        if (hwr) reinterpret_cast<uint16_t*>(hot + 8u * kRing + 2u * kRing)[hc] = (uint16_t)head;
+                    }
                     if ((CM & Cm & ~(rbelow | rbit)) == 0ull) heads[ctx] = (uint16_t)head;
                     uint32_t msl = mnode;
                     if (mnode & 0x10000u) msl = (head0 + (uint32_t)__popcll(CM & ((1ull << (mnode & 63u)) - 1ull)) + 1u) & (kRing - 1);
@@ -787,9 +835,14 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     }
 }
 
-void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks_all, hipStream_t s, bool all_level0, int nw, bool wide) {
+void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks_all, hipStream_t s, bool all_level0, int nw, bool wide, bool hot) {
     const bool prof = a.dbg != nullptr;
     const uint32_t nblocks = nblocks_all - a.blk0;
+    if (hot && all_level0 && wide && nw > 2 && nw <= 4) {        // the measured LDS-bucket variant (ZLNG_WG_HOT=1): NW = 4, wide plane, level 0
+        if (prof) hipLaunchKernelGGL((k_rolz_parse_wg<4, true, true, true, true>), dim3(nblocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_rolz_parse_wg<4, true, false, true, true>), dim3(nblocks), dim3(256), 0, s, a);
+        return;
+    }
     // kWide: slot plane form (zlng_common.h; the caller's k_dict_reset matches).  Only a level-0 context can use the wide form.
 #define ZLNG_WG_LAUNCH(NW)                                                                                                          \
     do {                                                                                                                            \

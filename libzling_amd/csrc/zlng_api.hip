@@ -208,10 +208,11 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
                  c->tok_cap, blk0, overflow_flag(c), settle_pf, lazy_fix};
     static const int wg_waves = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
     static const bool wg_wide = !(getenv("ZLNG_WG_COMPACT") && atoi(getenv("ZLNG_WG_COMPACT")) != 0);   // slot plane of the wg parser at level 0 (A/B switch)
+    static const bool wg_hot = getenv("ZLNG_WG_HOT") && atoi(getenv("ZLNG_WG_HOT")) != 0;     // LDS mirror of the hottest bucket (A/B switch; north_star's "LDS-staged buckets")
     const bool wide = c->level == 0 && (c->parser_kind == 2 || (c->parser_kind == 3 && wg_wide));
     launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, wide);
     timer_mark(c, "dict_reset");
-    if (c->parser_kind == 3) { pa.pf_waves = pf_env > 0 ? 1 : 0; launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves, wide); }
+    if (c->parser_kind == 3) { pa.pf_waves = pf_env > 0 ? 1 : 0; launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves, wide, wg_hot); }
     else if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
     else if (c->parser_kind == 0) { pa.pf_ahead = pipe_lead; pa.pf_waves = pipe_pf; launch_rolz_parse_pipe(pa, nb, c->stream, c->level == 0); }
     else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so

@@ -26,7 +26,7 @@ struct ParseArgs {
     int            lazy_fix;    // wave parser, level 0: resolve lazy-only conflicts in registers (1; 0 = replay them, ZLNG_LAZY_FIX)
 };
 // the workgroup-wide parser (rolz_wg.hip): nw wavefronts per block, window of 64 nw positions
-void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0, int nw, bool wide);   // wide: slot plane form at level 0
+void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0, int nw, bool wide, bool hot);   // wide: slot plane form at level 0; hot: one bucket mirrored in LDS
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide);   // wide: the slot plane form of the level-0 wave parser
 // both parse blocks [a.blk0, nblocks)
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
