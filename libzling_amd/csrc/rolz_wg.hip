@@ -804,7 +804,10 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 prevty = st & 0xFF;
                 nt += (uint32_t)limit; opos += limit + __popcll(MATu & Cm);
             }
-            serial_next = limit_hard;
+            // A hard token behind committed ones: at level 0 it is replayed by the serial code (3 K cycles); at levels 1-4 that replay
+            // is a walk of up to 16 dependent round trips by one wavefront (9-16 K cycles), and the next round, which starts AT the
+            // token, evaluates it as its lane 0 against the dictionary as it then is -- exact unless it conflicts with its own insert.
+            serial_next = limit_hard && (level0 || limit == 0 || a.min_restart < 0);
             if (limit == 0 && !limit_hard) overflow = true;         // cannot happen: a round commits a token or names a hard one
             // my bits of the last iteration's buffer
             if (dep_prev) {
