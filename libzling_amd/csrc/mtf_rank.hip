@@ -38,6 +38,12 @@ __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uin
 // SGPR on the constant bus, M0 as lane select is exempt: the lane goes through M0, written in the same
 // statement that reads it.  The lane values here are SALU results (s_ff1 / s_mul / s_lshr), so the
 // "VALU-written SGPR as lane select" wait states are not owed; SALU -> M0 -> v_writelane needs none.
+// M0 is a reserved register: an inline-asm clobber of it cannot be honoured by the compiler (clang warns that it "may lead to
+// undefined behaviour").  Settled on the ISA of this file's kernels (round 3, `hipcc -S`: every occurrence of m0 in mtf_rank.s is
+// one of the s_mov_b32 m0 / v_writelane ..., m0 pairs written here): no compiler-generated instruction reads or writes M0 -- gfx9
+// DS operations do not need it, nothing here uses s_movrel / GDS / s_sendmsg -- so nothing is live in M0 across these statements.
+// The clobber stays as the statement of intent.  (Saving M0 to a scratch SGPR and putting it back inside the statements was tried:
+// correct, and +5 % on the whole chain -- 834 vs 792 ms per GiB on one box, same call -- for no observable fault; not kept.)
 __device__ __forceinline__ void wrl(uint32_t& v, uint32_t val, uint32_t lane) {
     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane) : "m0");
 }
