@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
     uint64_t acc = 0;
     int nb = 0;
     uint32_t* tok = a.tok + sb.tok_off;
-    uint32_t nt = 0, tokv = 0, err = 0;
+    uint32_t nt = 0, tokv = 0, err = 0, outlen = 0;
     for (uint32_t i = 0; i < sb.rlen; i++) {
         if (nb < 32) {                                               // src/libzling.cpp:369-374
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(widx & 63));
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
         if (sym >= (uint32_t)kNsym1) { err = (uint32_t)(-ZLNG_DEC_E_CODE1); break; }
         const uint32_t l1 = len[sym];
         acc >>= l1; nb -= (int)l1;
-        uint32_t t = sym;
+        // a literal's token word carries its swap partner mtf_next(rank) in bits 16..23, so that the replay (one wavefront
+        // for the whole stream) does not have to compute it; the sub-block's decoded length is summed here for the same reason
+        uint32_t t = sym < 256 ? sym | mtf_next(sym) << 16 : sym;
+        outlen += sym < 256 ? 1u : (sym < 258 ? 2u : sym - 258u + (uint32_t)kMatchMin);
         if (sym >= 258) {                                            // src/libzling.cpp:386-401
             const uint32_t c = lut2[(uint32_t)acc & ((1u << kLut2Bits) - 1)];
             if (c >= (uint32_t)kNsym2) { err = (uint32_t)(-ZLNG_DEC_E_CODE2); break; }
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
     }
     if (lane < (nt & 63)) tok[(nt & ~63u) + lane] = tokv;
     // a failed sub-block is marked in its token count; the replay, which walks the stream in order, stops at the first one
-    if (lane == 0) a.sub_ntok[s] = err ? (0x80000000u | err) : nt;
+    if (lane == 0) { a.sub_ntok[s] = err ? (0x80000000u | err) : nt; a.sub_ntok[a.max_subs + s] = outlen; }
 }
 
 // ------------------------------------------------------------------------------ K9 ROLZ + MTF replay
@@ -283,10 +286,319 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
     for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_state)[i] = reinterpret_cast<const uint32_t*>(keep)[i];
 }
 
+
+// ------------------------------------------------------------------------------ K9, hand-written token loop
+// The same replay with the token loop of a sub-block written out by hand.  A lone wavefront issues one instruction every
+// ~5 cycles whatever it is, so the replay is bound by the instructions per token, not by bytes: the compiler's form above
+// spends ~100 per literal (it keeps every wave-uniform value in scalar registers and pays a v_readfirstlane and an exec
+// save/restore around every lane-0 store); this one runs the loop with EXEC = lane 0, keeps the context-derived addresses
+// in vector registers of that lane (an LDS read feeds the next LDS address without leaving the vector unit) and the
+// token-derived values (type, length, ring index: data-independent) in scalar registers, so that every branch is a scalar
+// branch.  Per literal: 33 instructions.  A match opens EXEC to 64 lanes for the copy only.
+//   heads[c] holds the NEXT slot of context c (= head + 1 mod 4096): one ds_inc_rtn_u32 returns the slot to write and
+//   steps the counter (src/libzling_lz.cpp:388-399 inserts before it looks up, so a ring index of 0 names the token itself
+//   and fails the src < pos test, as there).
+//   The per-token `pos + len > encpos` test of src/libzling_lz.cpp:336-369 is made once per sub-block: K8 sums the decoded
+//   length of its tokens (lengths do not depend on decoded data), and a sub-block whose sum does not land on encpos fails
+//   before a byte of it is written -- so the loop cannot write past the block.
+// LDS layout (one array, offsets fit the DS offset field): mru[256] u32 @0, heads[256] u32 @1024, mtf[256][256] u8 @2048.
+constexpr uint32_t kLdsMru = 0, kLdsHeads = 1024, kLdsMtf = 2048, kLdsReplay = kLdsMtf + 65536;
+
+__device__ __forceinline__ void replay_tokens(uint8_t* out, uint32_t* ring, const uint32_t* tok, uint32_t nt, uint32_t ti0, uint32_t lds_base,
+                                              uint32_t lane, uint32_t& opos, uint32_t& b1, uint32_t& b2, uint32_t& err) {
+    uint32_t o_opos, o_b1, o_b2, o_err;
+    auto uni64 = [](const void* p) {                                  // the "s" constraint wants values the compiler knows to be uniform
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
+    };
+    const uint64_t p_out = uni64(out), p_ring = uni64(ring), p_tok = uni64(tok);
+    asm volatile(R"(
+        s_mov_b64 s[60:61], exec
+        s_mov_b64 s[40:41], %[out]
+        s_mov_b64 s[42:43], %[ring]
+        s_mov_b64 s[44:45], %[tok]
+        s_mov_b32 s46, %[nt]
+        s_mov_b32 s47, %[ti]
+        s_mov_b32 s49, %[opos]
+        s_mov_b32 s62, %[ldsb]
+        s_mov_b32 s63, 0
+        v_mov_b32 v20, %[lane]
+        v_mov_b32 v28, %[b1]
+        v_mov_b32 v25, %[b2]
+        v_lshlrev_b32 v21, 2, v20
+        v_mov_b32 v38, 0xfff
+        v_mov_b32 v22, 0
+        v_mov_b32 v23, 0
+        v_add_u32 v41, 64, v20
+        v_cmpx_gt_u32 vcc, s46, v20
+        global_load_dword v22, v21, s[44:45]
+        s_mov_b64 exec, s[60:61]
+        v_cmpx_gt_u32 vcc, s46, v41
+        global_load_dword v23, v21, s[44:45] offset:256
+        s_mov_b64 exec, s[60:61]
+        s_add_u32 s44, s44, 0x200
+        s_addc_u32 s45, s45, 0
+        s_min_u32 s48, s46, 64
+        v_lshl_add_u32 v24, v28, 2, s62
+        v_lshl_add_u32 v26, v28, 8, s62
+        v_lshlrev_b32 v27, 14, v28
+        v_lshl_add_u32 v25, v25, 2, s62
+        v_mov_b32 v37, s49
+        s_waitcnt vmcnt(0)
+        s_mov_b64 exec, 1
+        s_branch L_bottom_%=
+
+    L_token_%=:
+        v_readlane_b32 s50, v22, s47
+        s_add_u32 s47, s47, 1
+        ds_inc_rtn_u32 v29, v24, v38 offset:1024
+        s_and_b32 s51, s50, 0xffff
+        s_lshr_b32 s52, s50, 16
+        s_cmpk_lt_u32 s51, 0x100
+        s_cbranch_scc0 L_notlit_%=
+
+        v_add_u32 v31, s51, v26
+        v_add_u32 v32, s52, v26
+        ds_read_u8 v33, v31 offset:2048
+        ds_read_u8 v34, v32 offset:2048
+        ds_read_b32 v35, v25
+        s_waitcnt lgkmcnt(0)
+        ds_write_b8 v31, v34 offset:2048
+        ds_write_b8 v32, v33 offset:2048
+        global_store_byte v37, v33, s[40:41]
+        v_lshl_add_u32 v30, v29, 2, v27
+        global_store_dword v30, v37, s[42:43]
+        v_lshl_or_b32 v36, v28, 8, v33
+        v_lshl_or_b32 v35, v35, 16, v36
+        ds_write_b32 v25, v35
+        v_mov_b32 v25, v24
+        v_mov_b32 v28, v33
+        v_lshl_add_u32 v24, v33, 2, s62
+        v_lshl_add_u32 v26, v33, 8, s62
+        v_lshlrev_b32 v27, 14, v33
+        s_add_u32 s49, s49, 1
+        v_add_u32 v37, 1, v37
+    L_bottom_%=:
+        s_cmp_lt_u32 s47, s48
+        s_cbranch_scc1 L_token_%=
+        s_cmp_ge_u32 s47, s46
+        s_cbranch_scc1 L_done_%=
+        s_mov_b64 exec, s[60:61]
+        s_waitcnt vmcnt(0)
+        v_mov_b32 v22, v23
+        s_add_u32 s48, s48, 64
+        s_min_u32 s48, s48, s46
+        s_add_u32 s56, s47, 64
+        v_add_u32 v41, s56, v20
+        v_mov_b32 v23, 0
+        v_cmpx_gt_u32 vcc, s46, v41
+        global_load_dword v23, v21, s[44:45]
+        s_add_u32 s44, s44, 0x100
+        s_addc_u32 s45, s45, 0
+        s_mov_b64 exec, 1
+        s_branch L_token_%=
+
+    L_notlit_%=:
+        s_cmpk_lt_u32 s51, 0x102
+        s_cbranch_scc0 L_match_%=
+        ds_read_b32 v35, v24
+        s_waitcnt lgkmcnt(0)
+        v_lshl_add_u32 v30, v29, 2, v27
+        global_store_dword v30, v37, s[42:43]
+        s_cmpk_eq_u32 s51, 0x100
+        s_cbranch_scc1 L_w0_%=
+        v_alignbit_b32 v35, v35, v35, 16
+        ds_write_b32 v24, v35
+    L_w0_%=:
+        v_bfe_u32 v33, v35, 8, 8
+        v_and_b32 v34, 0xff, v35
+        global_store_byte v37, v33, s[40:41]
+        global_store_byte v37, v34, s[40:41] offset:1
+        v_lshl_add_u32 v25, v33, 2, s62
+        v_mov_b32 v28, v34
+        v_lshl_add_u32 v24, v34, 2, s62
+        v_lshl_add_u32 v26, v34, 8, s62
+        v_lshlrev_b32 v27, 14, v34
+        s_add_u32 s49, s49, 2
+        v_add_u32 v37, 2, v37
+        s_branch L_bottom_%=
+
+    L_match_%=:
+        s_waitcnt lgkmcnt(0)
+        v_lshl_add_u32 v30, v29, 2, v27
+        global_store_dword v30, v37, s[42:43]
+        v_subrev_u32 v31, s52, v29
+        v_and_b32 v31, 0xfff, v31
+        v_lshl_add_u32 v31, v31, 2, v27
+        global_load_dword v32, v31, s[42:43]
+        s_sub_u32 s53, s51, 254
+        s_waitcnt vmcnt(0)
+        v_cmp_ge_u32 vcc, v32, v37
+        s_cbranch_vccnz L_err_%=
+        v_readfirstlane_b32 s54, v32
+        s_mov_b64 exec, s[60:61]
+        s_sub_u32 s55, s49, s54
+        s_cmp_ge_u32 s55, 64
+        s_cbranch_scc1 L_gen_%=
+        s_cmp_ge_u32 s55, s53
+        s_cbranch_scc1 L_gen_%=
+
+        v_cmpx_gt_u32 vcc, s55, v20
+        v_add_u32 v39, s54, v20
+        global_load_ubyte v42, v39, s[40:41]
+        s_mov_b32 s56, 0
+        s_waitcnt vmcnt(0)
+    L_per_%=:
+        s_sub_u32 s57, s53, s56
+        s_min_u32 s57, s57, s55
+        s_add_u32 s58, s49, s56
+        s_mov_b64 exec, s[60:61]
+        v_cmpx_gt_u32 vcc, s57, v20
+        v_add_u32 v40, s58, v20
+        global_store_byte v40, v42, s[40:41]
+        s_add_u32 s56, s56, s55
+        s_cmp_lt_u32 s56, s53
+        s_cbranch_scc1 L_per_%=
+        s_sub_u32 s56, s56, s55
+        s_sub_u32 s57, s53, 1
+        s_sub_u32 s57, s57, s56
+        s_sub_u32 s65, s55, 1
+        s_sub_u32 s66, s57, 1
+        s_cmp_eq_u32 s57, 0
+        s_cselect_b32 s66, s65, s66
+        s_sub_u32 s67, s66, 1
+        s_cmp_eq_u32 s66, 0
+        s_cselect_b32 s67, s65, s67
+        s_branch L_last3_%=
+
+    L_gen_%=:
+        s_mov_b32 s56, 0
+    L_cp_%=:
+        v_add_u32 v41, s56, v20
+        v_cmpx_gt_u32 vcc, s53, v41
+        v_add_u32 v39, s54, v41
+        v_add_u32 v40, s49, v41
+        global_load_ubyte v42, v39, s[40:41]
+        s_waitcnt vmcnt(0)
+        global_store_byte v40, v42, s[40:41]
+        s_mov_b64 exec, s[60:61]
+        s_add_u32 s56, s56, 64
+        s_cmp_lt_u32 s56, s53
+        s_cbranch_scc1 L_cp_%=
+        s_sub_u32 s57, s53, 1
+        s_sub_u32 s66, s53, 2
+        s_sub_u32 s67, s53, 3
+    L_last3_%=:
+        s_mov_b64 exec, s[60:61]
+        v_readlane_b32 s58, v42, s57
+        v_readlane_b32 s59, v42, s66
+        v_readlane_b32 s64, v42, s67
+        s_mov_b64 exec, 1
+        s_add_u32 s49, s49, s53
+        s_lshl_b32 s57, s64, 2
+        s_add_u32 s57, s57, s62
+        v_mov_b32 v31, s57
+        ds_read_b32 v35, v31
+        s_lshl_b32 s56, s59, 8
+        s_or_b32 s56, s56, s58
+        v_mov_b32 v37, s49
+        v_mov_b32 v28, s58
+        v_lshl_add_u32 v24, v28, 2, s62
+        v_lshl_add_u32 v26, v28, 8, s62
+        v_lshlrev_b32 v27, 14, v28
+        v_mov_b32 v25, s59
+        v_lshl_add_u32 v25, v25, 2, s62
+        s_waitcnt lgkmcnt(0)
+        v_and_b32 v36, 0xffff, v35
+        v_lshl_or_b32 v43, v35, 16, s56
+        v_cmp_ne_u32 vcc, s56, v36
+        v_cndmask_b32 v35, v35, v43, vcc
+        ds_write_b32 v31, v35
+        s_branch L_bottom_%=
+
+    L_err_%=:
+        s_mov_b32 s63, 1
+    L_done_%=:
+        s_mov_b64 exec, s[60:61]
+        s_waitcnt vmcnt(0) lgkmcnt(0)
+        v_subrev_u32 v25, s62, v25
+        v_lshrrev_b32 v25, 2, v25
+        s_nop 1
+        v_readfirstlane_b32 %[o_b1], v28
+        v_readfirstlane_b32 %[o_b2], v25
+        s_mov_b32 %[o_opos], s49
+        s_mov_b32 %[o_err], s63
+    )"
+        : [o_opos] "=s"(o_opos), [o_b1] "=s"(o_b1), [o_b2] "=s"(o_b2), [o_err] "=s"(o_err)
+        : [out] "s"(p_out), [ring] "s"(p_ring), [tok] "s"(p_tok), [nt] "s"(nt), [ti] "s"(ti0), [opos] "s"(opos), [ldsb] "s"(lds_base),
+          [lane] "v"(lane), [b1] "s"(b1), [b2] "s"(b2)
+        : "memory", "vcc", "scc",
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
+          "v40", "v41", "v42", "v43");
+    opos = o_opos; b1 = o_b1; b2 = o_b2; err = o_err;
+}
+
+__global__ __launch_bounds__(64) void k_rolz_replay(DecodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsReplay];
+    uint32_t* mru = reinterpret_cast<uint32_t*>(lds + kLdsMru);
+    uint32_t* heads = reinterpret_cast<uint32_t*>(lds + kLdsHeads);
+    uint8_t* mtf = lds + kLdsMtf;
+    const uint32_t lane = threadIdx.x;
+    auto ufl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const uint32_t lds_base = ufl((uint32_t)(uintptr_t)lds);
+    const uint32_t nblk = (uint32_t)a.summary[2];
+    for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(mtf)[i] = reinterpret_cast<const uint32_t*>(a.mtf_state)[i];
+    __syncthreads();
+    uint32_t err = 0;
+    for (uint32_t b = 0; b < nblk && !err; b++) {
+        const DecBlock bk = a.blocks[b];
+        uint8_t* out = a.out + bk.out_off;
+        for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_snap)[i] = reinterpret_cast<const uint32_t*>(mtf)[i];
+        for (uint32_t i = lane; i < 256u * kRing; i += 64) a.ring[i] = 0;  // Reset(), src/libzling_lz.cpp:378-386
+        for (uint32_t i = lane; i < 256; i += 64) heads[i] = 1;            // next slot = head + 1
+        __syncthreads();
+        uint32_t opos = 0;
+        for (uint32_t k = 0; k < bk.nsub && !err; k++) {
+            const DecSub sb = a.subs[bk.first_sub + k];
+            const uint32_t* tok = a.tok + sb.tok_off;
+            const uint32_t nt = ufl(a.sub_ntok[bk.first_sub + k]);
+            if (nt & 0x80000000u) { err = nt & 0xFFFFu; break; }           // K8 rejected this sub-block's bitstream
+            if (opos + ufl(a.sub_ntok[a.max_subs + bk.first_sub + k]) != sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+            for (uint32_t i = lane; i < 256; i += 64) mru[i] = 0;
+            __syncthreads();
+            uint32_t ti = 0;
+            while (opos < 2 && ti < nt) {                                  // first two bytes of a block are raw (src/libzling_lz.cpp:327-328)
+                const uint32_t v = ufl(tok[ti++]);
+                if ((v & 0xFFFF) >= 256) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+                if (lane == 0) out[opos] = (uint8_t)v;
+                opos++;
+            }
+            if (!err && ti < nt) {
+                uint32_t b1 = ufl(out[opos - 1]), b2 = ufl(out[opos - 2]), bad = 0, op = ufl(opos);
+                replay_tokens(out, a.ring, tok, nt, ufl(ti), lds_base, lane, op, b1, b2, bad);
+                opos = op;
+                if (bad) err = (uint32_t)(-ZLNG_DEC_E_LZ);
+            }
+            if (!err && opos != sb.encpos) err = (uint32_t)(-ZLNG_DEC_E_LZ);   // src/libzling_lz.cpp:371-373
+        }
+        if (err && lane == 0) { a.summary[5] = b; a.summary[6] = err; }
+    }
+    __syncthreads();
+    const uint8_t* keep = err ? a.mtf_snap : mtf;                    // a failed block leaves the tables as it found them
+    __threadfence_block();
+    for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_state)[i] = reinterpret_cast<const uint32_t*>(keep)[i];
+}
+
 void launch_frame_walk(const DecodeArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, s, a); }
 void launch_huff_decode(const DecodeArgs& a, uint32_t nsubs_upper, hipStream_t s) {
     hipLaunchKernelGGL(k_huff_decode, dim3(nsubs_upper), dim3(64), 0, s, a);
 }
-void launch_rolz_decode(const DecodeArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_rolz_decode, dim3(1), dim3(64), 0, s, a); }
+void launch_rolz_decode(const DecodeArgs& a, bool plain, hipStream_t s) {
+    if (plain) hipLaunchKernelGGL(k_rolz_decode, dim3(1), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_rolz_replay, dim3(1), dim3(64), 0, s, a);
+}
 
 }  // namespace zlng

@@ -76,6 +76,7 @@ struct zlng_ctx {
     uint8_t*  d_snap = nullptr;       // rank stage: table snapshots per 64-literal tile
     uint8_t*  d_tile_kk = nullptr;
     uint8_t*  d_nfr = nullptr;        // rank stage, front / back form: ranks of the literals outside the table front
+    int       dec_plain = 0;          // ZLNG_DEC=plain selects the compiler-scheduled replay loop (k_rolz_decode) instead of the hand-written one
     int       mtf_front = 0;          // ZLNG_MTF=front selects the front / back form of the chain (k_mtf_front: exact, measured slower -- DESIGN.md)
     // Measured ALTERNATIVE, off by default (ZLNG_HOST_RANK_CONTEXTS=k): the k longest rank chains of a
     // call are walked by host threads instead of by k_mtf_dense, overlapped with the device's other chains.  The product
@@ -492,6 +493,7 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     c->is_encode = is_encode != 0;
     c->max_blocks = (uint32_t)max_blocks;
     { const char* mk = getenv("ZLNG_MTF"); c->mtf_front = mk && strcmp(mk, "front") == 0; }
+    { const char* dk = getenv("ZLNG_DEC"); c->dec_plain = dk && strcmp(dk, "plain") == 0; }
     const char* pk = getenv("ZLNG_PARSER");
     c->parser_kind = !pk ? 3 : (strcmp(pk, "serial") == 0 ? 1 : (strcmp(pk, "pipe") == 0 ? 0 : (strcmp(pk, "wave") == 0 ? 2 : 3)));
     int rc = ZLNG_OK;
@@ -505,7 +507,7 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     if (!c->is_encode) {
         const size_t max_subs = nb * kDecSubsPerBlock;
         if ((rc = dev_alloc(c, &c->d_subs, max_subs)) || (rc = dev_alloc(c, &c->d_blocks, nb)) ||
-            (rc = dev_alloc(c, &c->d_sub_ntok, max_subs)) || (rc = dev_alloc(c, &c->d_ring, (size_t)256 * kRing)) ||
+            (rc = dev_alloc(c, &c->d_sub_ntok, 2 * max_subs)) || (rc = dev_alloc(c, &c->d_ring, (size_t)256 * kRing)) ||
             (rc = dev_alloc(c, &c->d_tok, nb * ((size_t)kTokCapMax + 64))) || (rc = dev_alloc(c, &c->d_summary, 8)))
             return fail(rc);
         c->h_blocks.resize(nb);
@@ -737,7 +739,7 @@ int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size
     if (nblk == 0) return sum[1] ? -(int)sum[1] : ZLNG_E_TRUNC;      // not even one complete block in the prefix
     launch_huff_decode(da, nsub, c->stream);
     timer_mark(c, "huff_decode");
-    launch_rolz_decode(da, c->stream);
+    launch_rolz_decode(da, c->dec_plain != 0, c->stream);
     timer_mark(c, "rolz_decode");
     CTX_HIP(hipMemcpyAsync(sum, c->d_summary, sizeof sum, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipMemcpyAsync(c->h_blocks.data(), c->d_blocks, nblk * sizeof(DecBlock), hipMemcpyDeviceToHost, c->stream));

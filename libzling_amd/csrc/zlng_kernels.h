@@ -107,6 +107,6 @@ struct DecodeArgs {
 };
 void launch_frame_walk(const DecodeArgs& a, hipStream_t s);
 void launch_huff_decode(const DecodeArgs& a, uint32_t nsubs, hipStream_t s);
-void launch_rolz_decode(const DecodeArgs& a, hipStream_t s);
+void launch_rolz_decode(const DecodeArgs& a, bool plain, hipStream_t s);   // plain: the compiler-scheduled token loop (ZLNG_DEC=plain)
 
 }  // namespace zlng
