@@ -13,6 +13,7 @@
 // therefore one wavefront per stream; its lanes cooperate on the match copies.
 #include "zlng_common.h"
 #include "zlng_kernels.h"
+#include "replay_loop.h"
 
 namespace zlng {
 
@@ -301,10 +302,14 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
 //   The per-token `pos + len > encpos` test of src/libzling_lz.cpp:336-369 is made once per sub-block: K8 sums the decoded
 //   length of its tokens (lengths do not depend on decoded data), and a sub-block whose sum does not land on encpos fails
 //   before a byte of it is written -- so the loop cannot write past the block.
-// LDS layout (one array, offsets fit the DS offset field): mru[256] u32 @0, heads[256] u32 @1024, mtf[256][256] u8 @2048.
-constexpr uint32_t kLdsMru = 0, kLdsHeads = 1024, kLdsMtf = 2048, kLdsReplay = kLdsMtf + 65536;
+//   The last 64 KiB of the block's output are mirrored in LDS (position p at window[p & 0xFFFF]): 71 % of the benchmark
+//   text's match sources lie that near, and a match served from the window waits for one LDS access instead of a second
+//   memory round trip behind the ring slot.  Every output byte is written to both.
+// LDS layout (the array must sit at LDS address 0; the kernel traps otherwise): mtf[256][256] u8 @0, window @0x10000,
+// mru[256] u32 @0x20000, heads[256] u32 @0x20400.
+constexpr uint32_t kLdsMtf = 0, kLdsWin = 0x10000, kLdsMru = 0x20000, kLdsHeads = 0x20400, kLdsReplay = 0x20800;
 
-__device__ __forceinline__ void replay_tokens(uint8_t* out, uint32_t* ring, const uint32_t* tok, uint32_t nt, uint32_t ti0, uint32_t lds_base,
+__device__ __forceinline__ void replay_tokens(uint8_t* out, uint32_t* ring, const uint32_t* tok, uint32_t nt, uint32_t ti0,
                                               uint32_t lane, uint32_t& opos, uint32_t& b1, uint32_t& b2, uint32_t& err) {
     uint32_t o_opos, o_b1, o_b2, o_err;
     auto uni64 = [](const void* p) {                                  // the "s" constraint wants values the compiler knows to be uniform
@@ -313,231 +318,22 @@ __device__ __forceinline__ void replay_tokens(uint8_t* out, uint32_t* ring, cons
                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
     };
     const uint64_t p_out = uni64(out), p_ring = uni64(ring), p_tok = uni64(tok);
-    asm volatile(R"(
-        s_mov_b64 s[60:61], exec
-        s_mov_b64 s[40:41], %[out]
-        s_mov_b64 s[42:43], %[ring]
-        s_mov_b64 s[44:45], %[tok]
-        s_mov_b32 s46, %[nt]
-        s_mov_b32 s47, %[ti]
-        s_mov_b32 s49, %[opos]
-        s_mov_b32 s62, %[ldsb]
-        s_mov_b32 s63, 0
-        v_mov_b32 v20, %[lane]
-        v_mov_b32 v28, %[b1]
-        v_mov_b32 v25, %[b2]
-        v_lshlrev_b32 v21, 2, v20
-        v_mov_b32 v38, 0xfff
-        v_mov_b32 v22, 0
-        v_mov_b32 v23, 0
-        v_add_u32 v41, 64, v20
-        v_cmpx_gt_u32 vcc, s46, v20
-        global_load_dword v22, v21, s[44:45]
-        s_mov_b64 exec, s[60:61]
-        v_cmpx_gt_u32 vcc, s46, v41
-        global_load_dword v23, v21, s[44:45] offset:256
-        s_mov_b64 exec, s[60:61]
-        s_add_u32 s44, s44, 0x200
-        s_addc_u32 s45, s45, 0
-        s_min_u32 s48, s46, 64
-        v_lshl_add_u32 v24, v28, 2, s62
-        v_lshl_add_u32 v26, v28, 8, s62
-        v_lshlrev_b32 v27, 14, v28
-        v_lshl_add_u32 v25, v25, 2, s62
-        v_mov_b32 v37, s49
-        s_waitcnt vmcnt(0)
-        s_mov_b64 exec, 1
-        s_branch L_bottom_%=
-
-    L_token_%=:
-        v_readlane_b32 s50, v22, s47
-        s_add_u32 s47, s47, 1
-        ds_inc_rtn_u32 v29, v24, v38 offset:1024
-        s_and_b32 s51, s50, 0xffff
-        s_lshr_b32 s52, s50, 16
-        s_cmpk_lt_u32 s51, 0x100
-        s_cbranch_scc0 L_notlit_%=
-
-        v_add_u32 v31, s51, v26
-        v_add_u32 v32, s52, v26
-        ds_read_u8 v33, v31 offset:2048
-        ds_read_u8 v34, v32 offset:2048
-        ds_read_b32 v35, v25
-        s_waitcnt lgkmcnt(0)
-        ds_write_b8 v31, v34 offset:2048
-        ds_write_b8 v32, v33 offset:2048
-        global_store_byte v37, v33, s[40:41]
-        v_lshl_add_u32 v30, v29, 2, v27
-        global_store_dword v30, v37, s[42:43]
-        v_lshl_or_b32 v36, v28, 8, v33
-        v_lshl_or_b32 v35, v35, 16, v36
-        ds_write_b32 v25, v35
-        v_mov_b32 v25, v24
-        v_mov_b32 v28, v33
-        v_lshl_add_u32 v24, v33, 2, s62
-        v_lshl_add_u32 v26, v33, 8, s62
-        v_lshlrev_b32 v27, 14, v33
-        s_add_u32 s49, s49, 1
-        v_add_u32 v37, 1, v37
-    L_bottom_%=:
-        s_cmp_lt_u32 s47, s48
-        s_cbranch_scc1 L_token_%=
-        s_cmp_ge_u32 s47, s46
-        s_cbranch_scc1 L_done_%=
-        s_mov_b64 exec, s[60:61]
-        s_waitcnt vmcnt(0)
-        v_mov_b32 v22, v23
-        s_add_u32 s48, s48, 64
-        s_min_u32 s48, s48, s46
-        s_add_u32 s56, s47, 64
-        v_add_u32 v41, s56, v20
-        v_mov_b32 v23, 0
-        v_cmpx_gt_u32 vcc, s46, v41
-        global_load_dword v23, v21, s[44:45]
-        s_add_u32 s44, s44, 0x100
-        s_addc_u32 s45, s45, 0
-        s_mov_b64 exec, 1
-        s_branch L_token_%=
-
-    L_notlit_%=:
-        s_cmpk_lt_u32 s51, 0x102
-        s_cbranch_scc0 L_match_%=
-        ds_read_b32 v35, v24
-        s_waitcnt lgkmcnt(0)
-        v_lshl_add_u32 v30, v29, 2, v27
-        global_store_dword v30, v37, s[42:43]
-        s_cmpk_eq_u32 s51, 0x100
-        s_cbranch_scc1 L_w0_%=
-        v_alignbit_b32 v35, v35, v35, 16
-        ds_write_b32 v24, v35
-    L_w0_%=:
-        v_bfe_u32 v33, v35, 8, 8
-        v_and_b32 v34, 0xff, v35
-        global_store_byte v37, v33, s[40:41]
-        global_store_byte v37, v34, s[40:41] offset:1
-        v_lshl_add_u32 v25, v33, 2, s62
-        v_mov_b32 v28, v34
-        v_lshl_add_u32 v24, v34, 2, s62
-        v_lshl_add_u32 v26, v34, 8, s62
-        v_lshlrev_b32 v27, 14, v34
-        s_add_u32 s49, s49, 2
-        v_add_u32 v37, 2, v37
-        s_branch L_bottom_%=
-
-    L_match_%=:
-        s_waitcnt lgkmcnt(0)
-        v_lshl_add_u32 v30, v29, 2, v27
-        global_store_dword v30, v37, s[42:43]
-        v_subrev_u32 v31, s52, v29
-        v_and_b32 v31, 0xfff, v31
-        v_lshl_add_u32 v31, v31, 2, v27
-        global_load_dword v32, v31, s[42:43]
-        s_sub_u32 s53, s51, 254
-        s_waitcnt vmcnt(0)
-        v_cmp_ge_u32 vcc, v32, v37
-        s_cbranch_vccnz L_err_%=
-        v_readfirstlane_b32 s54, v32
-        s_mov_b64 exec, s[60:61]
-        s_sub_u32 s55, s49, s54
-        s_cmp_ge_u32 s55, 64
-        s_cbranch_scc1 L_gen_%=
-        s_cmp_ge_u32 s55, s53
-        s_cbranch_scc1 L_gen_%=
-
-        v_cmpx_gt_u32 vcc, s55, v20
-        v_add_u32 v39, s54, v20
-        global_load_ubyte v42, v39, s[40:41]
-        s_mov_b32 s56, 0
-        s_waitcnt vmcnt(0)
-    L_per_%=:
-        s_sub_u32 s57, s53, s56
-        s_min_u32 s57, s57, s55
-        s_add_u32 s58, s49, s56
-        s_mov_b64 exec, s[60:61]
-        v_cmpx_gt_u32 vcc, s57, v20
-        v_add_u32 v40, s58, v20
-        global_store_byte v40, v42, s[40:41]
-        s_add_u32 s56, s56, s55
-        s_cmp_lt_u32 s56, s53
-        s_cbranch_scc1 L_per_%=
-        s_sub_u32 s56, s56, s55
-        s_sub_u32 s57, s53, 1
-        s_sub_u32 s57, s57, s56
-        s_sub_u32 s65, s55, 1
-        s_sub_u32 s66, s57, 1
-        s_cmp_eq_u32 s57, 0
-        s_cselect_b32 s66, s65, s66
-        s_sub_u32 s67, s66, 1
-        s_cmp_eq_u32 s66, 0
-        s_cselect_b32 s67, s65, s67
-        s_branch L_last3_%=
-
-    L_gen_%=:
-        s_mov_b32 s56, 0
-    L_cp_%=:
-        v_add_u32 v41, s56, v20
-        v_cmpx_gt_u32 vcc, s53, v41
-        v_add_u32 v39, s54, v41
-        v_add_u32 v40, s49, v41
-        global_load_ubyte v42, v39, s[40:41]
-        s_waitcnt vmcnt(0)
-        global_store_byte v40, v42, s[40:41]
-        s_mov_b64 exec, s[60:61]
-        s_add_u32 s56, s56, 64
-        s_cmp_lt_u32 s56, s53
-        s_cbranch_scc1 L_cp_%=
-        s_sub_u32 s57, s53, 1
-        s_sub_u32 s66, s53, 2
-        s_sub_u32 s67, s53, 3
-    L_last3_%=:
-        s_mov_b64 exec, s[60:61]
-        v_readlane_b32 s58, v42, s57
-        v_readlane_b32 s59, v42, s66
-        v_readlane_b32 s64, v42, s67
-        s_mov_b64 exec, 1
-        s_add_u32 s49, s49, s53
-        s_lshl_b32 s57, s64, 2
-        s_add_u32 s57, s57, s62
-        v_mov_b32 v31, s57
-        ds_read_b32 v35, v31
-        s_lshl_b32 s56, s59, 8
-        s_or_b32 s56, s56, s58
-        v_mov_b32 v37, s49
-        v_mov_b32 v28, s58
-        v_lshl_add_u32 v24, v28, 2, s62
-        v_lshl_add_u32 v26, v28, 8, s62
-        v_lshlrev_b32 v27, 14, v28
-        v_mov_b32 v25, s59
-        v_lshl_add_u32 v25, v25, 2, s62
-        s_waitcnt lgkmcnt(0)
-        v_and_b32 v36, 0xffff, v35
-        v_lshl_or_b32 v43, v35, 16, s56
-        v_cmp_ne_u32 vcc, s56, v36
-        v_cndmask_b32 v35, v35, v43, vcc
-        ds_write_b32 v31, v35
-        s_branch L_bottom_%=
-
-    L_err_%=:
-        s_mov_b32 s63, 1
-    L_done_%=:
-        s_mov_b64 exec, s[60:61]
-        s_waitcnt vmcnt(0) lgkmcnt(0)
-        v_subrev_u32 v25, s62, v25
-        v_lshrrev_b32 v25, 2, v25
-        s_nop 1
-        v_readfirstlane_b32 %[o_b1], v28
-        v_readfirstlane_b32 %[o_b2], v25
-        s_mov_b32 %[o_opos], s49
-        s_mov_b32 %[o_err], s63
-    )"
+    // The loop itself is generated (scripts/gen_replay_asm.py -> replay_loop.h): it is software-pipelined over two register
+    // sets, so that the LDS reads of token t+1 are in flight while token t is written out.  Shared registers: s[40:41] out,
+    // s[42:43] ring, s[44:45] next token window, s46 nt, s47 index of the next token to fetch, s48 end of the window held in
+    // v22 (v23: the one after), s49 pos, s53 match length, s54 source, s55 distance, s[60:61] EXEC at entry, s62 &mru[],
+    // s63 error, s68 &window; v20 lane, v21 lane*4, v37 pos (lane 0), v38 4095, v45 0xFFFF.  Per set (A / B): token, symbol,
+    // ring index or swap partner (s50-52 / s70-72); &mru[b1] (heads[b1] at +1024), &mru[b2], table row b1*256, ring row
+    // b1<<14, b1, ring slot, the two table addresses and entries, the MRU pair (v24-29, v31-35 / v54-59, v61-65).
+    asm volatile(ZLNG_REPLAY_LOOP_ASM
         : [o_opos] "=s"(o_opos), [o_b1] "=s"(o_b1), [o_b2] "=s"(o_b2), [o_err] "=s"(o_err)
-        : [out] "s"(p_out), [ring] "s"(p_ring), [tok] "s"(p_tok), [nt] "s"(nt), [ti] "s"(ti0), [opos] "s"(opos), [ldsb] "s"(lds_base),
+        : [out] "s"(p_out), [ring] "s"(p_ring), [tok] "s"(p_tok), [nt] "s"(nt), [ti] "s"(ti0), [opos] "s"(opos),
           [lane] "v"(lane), [b1] "s"(b1), [b2] "s"(b2)
         : "memory", "vcc", "scc",
           "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
-          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
-          "v40", "v41", "v42", "v43");
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v54", "v55", "v56", "v57", "v58", "v59", "v61", "v62", "v63", "v64", "v65");
     opos = o_opos; b1 = o_b1; b2 = o_b2; err = o_err;
 }
 
@@ -546,9 +342,10 @@ __global__ __launch_bounds__(64) void k_rolz_replay(DecodeArgs a) {
     uint32_t* mru = reinterpret_cast<uint32_t*>(lds + kLdsMru);
     uint32_t* heads = reinterpret_cast<uint32_t*>(lds + kLdsHeads);
     uint8_t* mtf = lds + kLdsMtf;
+    uint8_t* win = lds + kLdsWin;
     const uint32_t lane = threadIdx.x;
     auto ufl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    const uint32_t lds_base = ufl((uint32_t)(uintptr_t)lds);
+    if ((uint32_t)(uintptr_t)lds != 0) __builtin_trap();               // the token loop addresses LDS absolutely
     const uint32_t nblk = (uint32_t)a.summary[2];
     for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(mtf)[i] = reinterpret_cast<const uint32_t*>(a.mtf_state)[i];
     __syncthreads();
@@ -559,6 +356,9 @@ __global__ __launch_bounds__(64) void k_rolz_replay(DecodeArgs a) {
         for (uint32_t i = lane; i < 256 * 256 / 4; i += 64) reinterpret_cast<uint32_t*>(a.mtf_snap)[i] = reinterpret_cast<const uint32_t*>(mtf)[i];
         for (uint32_t i = lane; i < 256u * kRing; i += 64) a.ring[i] = 0;  // Reset(), src/libzling_lz.cpp:378-386
         for (uint32_t i = lane; i < 256; i += 64) heads[i] = 1;            // next slot = head + 1
+        // the token loop reads ring slots with scalar loads (they do not queue behind the stores in flight) and only bounds
+        // how many vector operations may still be outstanding: the reset must have landed before it starts
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         uint32_t opos = 0;
         for (uint32_t k = 0; k < bk.nsub && !err; k++) {
@@ -573,12 +373,12 @@ __global__ __launch_bounds__(64) void k_rolz_replay(DecodeArgs a) {
             while (opos < 2 && ti < nt) {                                  // first two bytes of a block are raw (src/libzling_lz.cpp:327-328)
                 const uint32_t v = ufl(tok[ti++]);
                 if ((v & 0xFFFF) >= 256) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
-                if (lane == 0) out[opos] = (uint8_t)v;
+                if (lane == 0) { out[opos] = (uint8_t)v; win[opos] = (uint8_t)v; }
                 opos++;
             }
             if (!err && ti < nt) {
                 uint32_t b1 = ufl(out[opos - 1]), b2 = ufl(out[opos - 2]), bad = 0, op = ufl(opos);
-                replay_tokens(out, a.ring, tok, nt, ufl(ti), lds_base, lane, op, b1, b2, bad);
+                replay_tokens(out, a.ring, tok, nt, ufl(ti), lane, op, b1, b2, bad);
                 opos = op;
                 if (bad) err = (uint32_t)(-ZLNG_DEC_E_LZ);
             }
