@@ -46,7 +46,7 @@ METRIC_DECODE = "decode MB/s (output) of the e0 enwik9 .zlng; bit-exact round tr
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 RANK_STAGES = ("lit_partition", "mtf_chain", "rank_replay", "mtf_rank")      # one launch group: the first three; several: mtf_rank
 KERNEL_OF_STAGE = {"rolz_parse": "k_rolz_parse_wg", "mtf_rank": "k_mtf_dense", "mtf_chain": "k_mtf_dense", "rank_replay": "k_mtf_replay", "huff_pack": "k_pack", "huff_lengths": "k_lengths",
-                   "histogram": "k_histogram", "huff_decode": "k_huff_decode", "rolz_decode": "k_rolz_decode", "frame_walk": "k_frame_walk"}
+                   "histogram": "k_histogram", "huff_decode": "k_huff_decode", "rolz_decode": "k_rolz_replay", "frame_walk": "k_frame_walk"}
 
 
 ENCODE_KERNEL_SOURCES = ("zlng_common.h", "zlng_kernels.h", "rolz_dev.h", "rolz_wg.hip", "mtf_rank.hip", "huffman.hip")

@@ -297,8 +297,8 @@ __global__ __launch_bounds__(64) void k_rolz_decode(DecodeArgs a) {
 // token-derived values (type, length, ring index: data-independent) in scalar registers, so that every branch is a scalar
 // branch.  Per literal: 33 instructions.  A match opens EXEC to 64 lanes for the copy only.
 //   heads[c] holds the NEXT slot of context c (= head + 1 mod 4096): one ds_inc_rtn_u32 returns the slot to write and
-//   steps the counter (src/libzling_lz.cpp:388-399 inserts before it looks up, so a ring index of 0 names the token itself
-//   and fails the src < pos test, as there).
+//   steps the counter (src/libzling_lz.cpp:388-399 inserts before it looks up, so a ring index of 0 names the token itself:
+//   rejected, like k_rolz_decode's src >= pos).
 //   The per-token `pos + len > encpos` test of src/libzling_lz.cpp:336-369 is made once per sub-block: K8 sums the decoded
 //   length of its tokens (lengths do not depend on decoded data), and a sub-block whose sum does not land on encpos fails
 //   before a byte of it is written -- so the loop cannot write past the block.

@@ -195,14 +195,15 @@ def notlit(X):
     # scalar cache is not coherent with vector stores, hence s_dcache_inv; the slot read was stored `index` tokens ago and
     # every token since issued at least one vector store, so "at most index - 1 vector operations outstanding" proves that
     # store has landed (s_waitcnt vmcnt is in order): three classes of the index, the common one (>= 17) hardly ever waits.
+    # Index 0 names the token itself (GetMatchAndUpdate inserts before it looks up, src/libzling_lz.cpp:388-399; the reference
+    # would copy the match onto itself, this decoder has always rejected it: "src >= pos" in k_rolz_decode); the END symbol
+    # of the look-ahead carries index 0 as well, so both are told apart off the main path.
     emit(f"""
     NOTLIT_{X}_%=:
         v_readfirstlane_b32 s57, {r['b1']}
         s_waitcnt lgkmcnt(0)
         s_cmpk_lt_u32 {r['sym']}, 0x102
         s_cbranch_scc1 WORD_{X}_%=
-        s_cmpk_eq_u32 {r['sym']}, 0xffff
-        s_cbranch_scc1 DONE_{X}_%=
         v_readfirstlane_b32 s56, {r['slot']}
         s_cmpk_lt_u32 {r['aux']}, 17
         s_cbranch_scc1 NEAR_{X}_%=
@@ -233,6 +234,8 @@ def notlit(X):
         s_waitcnt vmcnt(4)
         s_branch RL_{X}_%=
     NEAR0_{X}_%=:
+        s_cmpk_eq_u32 {r['sym']}, 0xffff
+        s_cbranch_scc1 DONE_{X}_%=
         s_cmp_eq_u32 {r['aux']}, 0
         s_cbranch_scc1 ERR_%=
         s_waitcnt vmcnt(0)
