@@ -318,6 +318,77 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
           [p15] "s"(pk[15])                                                                                     \
         : "vcc", "scc", "s98", "s99", "m0")
 
+// ---- re-entrant recording tile: ZLNG_MTF_TILE's steps, entered at step `ent` through a table of branches, without the
+// next tile's load.  It is what finishes a tile of the chain after a literal of rank >= 64 made the state-only form below
+// leave: the literal is dealt with outside (slow_step), then the rest of the tile runs here at the speed of the recording
+// step instead of the compiler-scheduled ZLNG_MTF_STEP loop (source text: 85 % of the blank's tiles meet such a literal,
+// 3.5 of them per tile -- scripts/ctx_probe.py --real).  Like ZLNG_MTF_S_SLOW its out-of-line part notes K + 1 in lv first,
+// so a further rank >= 64 is identified on the way out (label 9); lv = 0 means the tile is finished.  SCC is set before the
+// jump (entering a step means "no slow path pending"); the seven SALU instructions of the jump also keep the DPP read of t0
+// clear of a v_writelane that slow_step may have issued last.
+#define ZLNG_MTF_R_SLOW(PK, B, K, KN)                                                                           \
+    "1" #K ":\n\t"                                                                                              \
+    "s_mov_b32 %[lv], " #K "+1\n\t"                                                                             \
+    "v_cmp_eq_u32_sdwa vcc, %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
+    "s_bfe_u32 %[d], %[" #PK "], (8 * " #B ") | (8 << 16)\n\t"                                                  \
+    "s_cbranch_vccz 9f\n\t"                                                                                     \
+    "s_ff1_i32_b64 %[nx], vcc\n\t"                                                                              \
+    "s_add_u32 %[i], %[nx], 1\n\t"                                                                              \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "s_mul_i32 %[nx], %[i], 0xf337\n\t"                                                                         \
+    "v_readlane_b32 %[da], %[t0], %[i]\n\t"                                                                     \
+    "s_lshr_b32 %[nx], %[nx], 16\n\t"                                                                           \
+    "v_readlane_b32 %[db], %[t0], %[nx]\n\t"                                                                    \
+    "v_writelane_b32 %[t0], %[da], m0\n\t"                                                                      \
+    "s_mov_b32 m0, %[i]\n\t"                                                                                    \
+    "v_writelane_b32 %[t0], %[db], m0\n\t"                                                                      \
+    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
+    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
+    "s_bitset1_b32 %[i], 31\n\t"                                                                                \
+    "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
+    "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
+    "s_branch 2" #KN "b\n\t"
+#define ZLNG_MTF_R_COLD(PK, A, B, C, D, N)                                                                      \
+    ZLNG_MTF_R_SLOW(PK, 0, A, B) ZLNG_MTF_R_SLOW(PK, 1, B, C) ZLNG_MTF_R_SLOW(PK, 2, C, D) ZLNG_MTF_R_SLOW(PK, 3, D, N)
+#define ZLNG_MTF_TILE_RE(PKIN, ENT)                                                                             \
+    asm volatile(                                                                                               \
+        "s_getpc_b64 s[98:99]\n\t"                                                                              \
+        "s_lshl_b32 %[i], %[ent], 2\n\t"                                                                        \
+        "s_add_u32 %[i], %[i], 24\n\t"            /* the six 4-byte instructions from here to the table */      \
+        "s_add_u32 s98, s98, %[i]\n\t"                                                                          \
+        "s_addc_u32 s99, s99, 0\n\t"                                                                            \
+        "s_cmp_eq_u32 0, 0\n\t"                                                                                 \
+        "s_setpc_b64 s[98:99]\n\t"                                                                              \
+        "s_branch 20f\n\t" "s_branch 21f\n\t" "s_branch 22f\n\t" "s_branch 23f\n\t" "s_branch 24f\n\t" "s_branch 25f\n\t" "s_branch 26f\n\t" "s_branch 27f\n\t" "s_branch 28f\n\t" "s_branch 29f\n\t" "s_branch 210f\n\t" "s_branch 211f\n\t" "s_branch 212f\n\t" "s_branch 213f\n\t" "s_branch 214f\n\t" "s_branch 215f\n\t" "s_branch 216f\n\t" "s_branch 217f\n\t" "s_branch 218f\n\t" "s_branch 219f\n\t" "s_branch 220f\n\t" "s_branch 221f\n\t" "s_branch 222f\n\t" "s_branch 223f\n\t" "s_branch 224f\n\t" "s_branch 225f\n\t" "s_branch 226f\n\t" "s_branch 227f\n\t" "s_branch 228f\n\t" "s_branch 229f\n\t" "s_branch 230f\n\t" "s_branch 231f\n\t" "s_branch 232f\n\t" "s_branch 233f\n\t" "s_branch 234f\n\t" "s_branch 235f\n\t" "s_branch 236f\n\t" "s_branch 237f\n\t" "s_branch 238f\n\t" "s_branch 239f\n\t" "s_branch 240f\n\t" "s_branch 241f\n\t" "s_branch 242f\n\t" "s_branch 243f\n\t" "s_branch 244f\n\t" "s_branch 245f\n\t" "s_branch 246f\n\t" "s_branch 247f\n\t" "s_branch 248f\n\t" "s_branch 249f\n\t" "s_branch 250f\n\t" "s_branch 251f\n\t" "s_branch 252f\n\t" "s_branch 253f\n\t" "s_branch 254f\n\t" "s_branch 255f\n\t" "s_branch 256f\n\t" "s_branch 257f\n\t" "s_branch 258f\n\t" "s_branch 259f\n\t" "s_branch 260f\n\t" "s_branch 261f\n\t" "s_branch 262f\n\t" "s_branch 263f\n\t" \
+        ZLNG_MTF_G_FAST(p0, 19, 0, 1, 2, 3)  ZLNG_MTF_G_FAST(p1, 3, 4, 5, 6, 7) \
+        ZLNG_MTF_G_FAST(p2, 7, 8, 9, 10, 11)  ZLNG_MTF_G_FAST(p3, 11, 12, 13, 14, 15) \
+        ZLNG_MTF_G_FAST(p4, 15, 16, 17, 18, 19)  ZLNG_MTF_G_FAST(p5, 19, 20, 21, 22, 23) \
+        ZLNG_MTF_G_FAST(p6, 23, 24, 25, 26, 27)  ZLNG_MTF_G_FAST(p7, 27, 28, 29, 30, 31) \
+        ZLNG_MTF_G_FAST(p8, 31, 32, 33, 34, 35)  ZLNG_MTF_G_FAST(p9, 35, 36, 37, 38, 39) \
+        ZLNG_MTF_G_FAST(p10, 39, 40, 41, 42, 43)  ZLNG_MTF_G_FAST(p11, 43, 44, 45, 46, 47) \
+        ZLNG_MTF_G_FAST(p12, 47, 48, 49, 50, 51)  ZLNG_MTF_G_FAST(p13, 51, 52, 53, 54, 55) \
+        ZLNG_MTF_G_FAST(p14, 55, 56, 57, 58, 59)  ZLNG_MTF_G_FAST(p15, 59, 60, 61, 62, 63) \
+        "264:\n\t"                                                                                              \
+        "s_cbranch_scc0 163f\n\t"                                                                               \
+        "s_mov_b32 %[lv], 0\n\t"                                                                                \
+        "s_branch 9f\n\t"                                                                                       \
+        ZLNG_MTF_R_COLD(p0, 0, 1, 2, 3, 4)  ZLNG_MTF_R_COLD(p1, 4, 5, 6, 7, 8) \
+        ZLNG_MTF_R_COLD(p2, 8, 9, 10, 11, 12)  ZLNG_MTF_R_COLD(p3, 12, 13, 14, 15, 16) \
+        ZLNG_MTF_R_COLD(p4, 16, 17, 18, 19, 20)  ZLNG_MTF_R_COLD(p5, 20, 21, 22, 23, 24) \
+        ZLNG_MTF_R_COLD(p6, 24, 25, 26, 27, 28)  ZLNG_MTF_R_COLD(p7, 28, 29, 30, 31, 32) \
+        ZLNG_MTF_R_COLD(p8, 32, 33, 34, 35, 36)  ZLNG_MTF_R_COLD(p9, 36, 37, 38, 39, 40) \
+        ZLNG_MTF_R_COLD(p10, 40, 41, 42, 43, 44)  ZLNG_MTF_R_COLD(p11, 44, 45, 46, 47, 48) \
+        ZLNG_MTF_R_COLD(p12, 48, 49, 50, 51, 52)  ZLNG_MTF_R_COLD(p13, 52, 53, 54, 55, 56) \
+        ZLNG_MTF_R_COLD(p14, 56, 57, 58, 59, 60)  ZLNG_MTF_R_COLD(p15, 60, 61, 62, 63, 64) \
+        "9:\n\t"                                                                                                \
+        : [t0] "+v"(t0), [up] "+v"(up), [ranks] "+v"(ranks), [m1] "=&s"(m1_), [i] "=&s"(i_), [nx] "=&s"(nx_),   \
+          [d] "=&s"(d_), [da] "=&s"(da_), [db] "=&s"(db_), [lv] "=&s"(lv_)                                      \
+        : [ent] "s"(ENT), [p0] "s"(PKIN[0]), [p1] "s"(PKIN[1]), [p2] "s"(PKIN[2]), [p3] "s"(PKIN[3]),           \
+          [p4] "s"(PKIN[4]), [p5] "s"(PKIN[5]), [p6] "s"(PKIN[6]), [p7] "s"(PKIN[7]), [p8] "s"(PKIN[8]), [p9] "s"(PKIN[9]), \
+          [p10] "s"(PKIN[10]), [p11] "s"(PKIN[11]), [p12] "s"(PKIN[12]), [p13] "s"(PKIN[13]), [p14] "s"(PKIN[14]), \
+          [p15] "s"(PKIN[15])                                                                                   \
+        : "vcc", "scc", "s98", "s99", "m0")
+
 // ---- state-only form of the tile (what the hottest chains run).  The serial chain is bound by instructions per literal
 // (scripts/ubench/mtfstep.hip: 19.1 ns per literal with the rank record, 17.0 without; the two SALU instructions that
 // are left -- slow-path test and its late branch -- cost 6.4 ns of that, the five-instruction table chain alone 10.7),
@@ -404,18 +475,71 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
     }
     uint8_t* st = a.state + ctx * 256;
     uint32_t t0 = st[lane], t1 = st[64 + lane], t2 = st[128 + lane], t3 = st[192 + lane];
+    const uint64_t tstart = a.dbg ? __builtin_readcyclecounter() : 0;   // ZLNG_PROFILE=1 (scripts/ctx_probe.py): cycles and rank >= 64 events per context
+    uint64_t n_ev = 0;
 
-    auto slow_step = [&](uint32_t c) __attribute__((always_inline)) -> uint32_t {                     // rank >= 64
-        const uint64_t m1 = __ballot(t1 == c), m2 = __ballot(t2 == c), m3 = __ballot(t3 == c);
-        const uint32_t i = m1 ? 64 + (uint32_t)__builtin_ctzll(m1)
-                              : (m2 ? 128 + (uint32_t)__builtin_ctzll(m2) : 192 + (uint32_t)__builtin_ctzll(m3));
-        const uint32_t nx = mtf_next_fast(i);
-        uint32_t d;
-        switch (nx >> 6) { case 0: d = rdl(t0, nx & 63); break; case 1: d = rdl(t1, nx & 63); break;
-                           case 2: d = rdl(t2, nx & 63); break; default: d = rdl(t3, nx & 63); break; }
-        switch (i >> 6) { case 1: wrl(t1, d, i & 63); break; case 2: wrl(t2, d, i & 63); break; default: wrl(t3, d, i & 63); break; }
-        switch (nx >> 6) { case 0: wrl(t0, c, nx & 63); break; case 1: wrl(t1, c, nx & 63); break;
-                           case 2: wrl(t2, c, nx & 63); break; default: wrl(t3, c, nx & 63); break; }
+    // rank >= 64: c is not in t0.  Straight-line (the compiler's form of the same thing -- four-way switches on the register
+    // that holds a position -- came out at ~80 instructions with a dozen taken branches, ~0.4 us on a lone wavefront):
+    // the position from three compares, d = table[next] by three v_readlane and two selects (next = mtfnext(i) lies in 60..140),
+    // the two stores as v_cndmask under a one-hot lane mask that is zero for the registers the position is not in.
+    auto slow_step = [&](uint32_t c) __attribute__((always_inline)) -> uint32_t {
+        uint64_t ma, mb, mc, oh;
+        uint32_t i, nx, a, b, d, d0, d1, vd;
+        asm volatile(
+            "v_cmp_eq_u32_e64 %[ma], %[c], %[t1]\n\t"
+            "v_cmp_eq_u32_e64 %[mb], %[c], %[t2]\n\t"
+            "v_cmp_eq_u32_e64 %[mc], %[c], %[t3]\n\t"
+            "s_ff1_i32_b64 %[a], %[ma]\n\t"
+            "s_ff1_i32_b64 %[b], %[mb]\n\t"
+            "s_ff1_i32_b64 %[i], %[mc]\n\t"
+            "s_add_u32 %[i], %[i], 0xc0\n\t"
+            "s_add_u32 %[nx], %[b], 0x80\n\t"
+            "s_cmp_lt_i32 %[b], 0\n\t"
+            "s_cselect_b32 %[i], %[i], %[nx]\n\t"
+            "s_add_u32 %[nx], %[a], 64\n\t"
+            "s_cmp_lt_i32 %[a], 0\n\t"
+            "s_cselect_b32 %[i], %[i], %[nx]\n\t"
+            "s_mov_b32 %[a], 0xf337\n\t"                      /* mtf_next_fast */
+            "s_mov_b32 %[b], 0x8ccf\n\t"
+            "s_cmpk_lt_u32 %[i], 0x80\n\t"
+            "s_cselect_b32 %[a], %[a], %[b]\n\t"
+            "s_mul_i32 %[nx], %[i], %[a]\n\t"
+            "s_lshr_b32 %[nx], %[nx], 16\n\t"
+            "v_readlane_b32 %[d0], %[t0], %[nx]\n\t"          /* lane select = nx & 63 */
+            "v_readlane_b32 %[d1], %[t1], %[nx]\n\t"
+            "v_readlane_b32 %[d], %[t2], %[nx]\n\t"
+            "s_cmpk_lt_u32 %[nx], 0x80\n\t"
+            "s_cselect_b32 %[d], %[d1], %[d]\n\t"
+            "s_cmpk_lt_u32 %[nx], 0x40\n\t"
+            "s_cselect_b32 %[d], %[d0], %[d]\n\t"
+            "v_mov_b32 %[vd], %[d]\n\t"                       /* table[i] = d */
+            "s_lshl_b64 %[oh], 1, %[i]\n\t"
+            "s_lshr_b32 %[a], %[i], 6\n\t"
+            "s_cmp_eq_u32 %[a], 1\n\t"
+            "s_cselect_b64 %[ma], %[oh], 0\n\t"
+            "s_cmp_eq_u32 %[a], 2\n\t"
+            "s_cselect_b64 %[mb], %[oh], 0\n\t"
+            "s_cmp_eq_u32 %[a], 3\n\t"
+            "s_cselect_b64 %[mc], %[oh], 0\n\t"
+            "v_cndmask_b32_e64 %[t1], %[t1], %[vd], %[ma]\n\t"
+            "v_cndmask_b32_e64 %[t2], %[t2], %[vd], %[mb]\n\t"
+            "v_cndmask_b32_e64 %[t3], %[t3], %[vd], %[mc]\n\t"
+            "v_mov_b32 %[vd], %[c]\n\t"                       /* table[next] = c */
+            "s_lshl_b64 %[oh], 1, %[nx]\n\t"
+            "s_lshr_b32 %[a], %[nx], 6\n\t"
+            "s_cmp_eq_u32 %[a], 0\n\t"
+            "s_cselect_b64 %[ma], %[oh], 0\n\t"
+            "s_cmp_eq_u32 %[a], 1\n\t"
+            "s_cselect_b64 %[mb], %[oh], 0\n\t"
+            "s_cmp_eq_u32 %[a], 2\n\t"
+            "s_cselect_b64 %[mc], %[oh], 0\n\t"
+            "v_cndmask_b32_e64 %[t0], %[t0], %[vd], %[ma]\n\t"
+            "v_cndmask_b32_e64 %[t1], %[t1], %[vd], %[mb]\n\t"
+            "v_cndmask_b32_e64 %[t2], %[t2], %[vd], %[mc]\n\t"
+            : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [ma] "=&s"(ma), [mb] "=&s"(mb), [mc] "=&s"(mc), [oh] "=&s"(oh),
+              [i] "=&s"(i), [nx] "=&s"(nx), [a] "=&s"(a), [b] "=&s"(b), [d] "=&s"(d), [d0] "=&s"(d0), [d1] "=&s"(d1), [vd] "=&v"(vd)
+            : [c] "s"(c)
+            : "scc");
         return i;
     };
 
@@ -437,13 +561,21 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
         snap[(BASE) + lane] = (uint8_t)t0;          /* table front at the start of the tile, for k_mtf_replay */   \
         ZLNG_MTF_TILE_S(PKIN, NXTOUT);                                                                             \
         if (__builtin_expect(lv_ != 0, 0)) {        /* literal lv_ - 1 has rank >= 64: the statement stopped there */ \
-            uint32_t ranks = 0;                                                                                    \
+            uint32_t ranks = 0;                     /* one-hot word or 0x80000000 | rank per lane, as ZLNG_MTF_TILE records */ \
             const uint32_t kk = lv_ - 1;                                                                           \
-            const uint32_t v = run[(BASE) + lane];                                                                 \
-            const uint32_t r = slow_step(rdl(v, kk));                                                              \
-            wrl(ranks, r, kk);                                                                                     \
-            for (uint32_t k = kk + 1; k < 64u; k++) ZLNG_MTF_STEP(k)                                               \
-            if (lane >= kk) run[(BASE) + lane] = (uint8_t)ranks;   /* lanes below kk keep their literal for the replay */ \
+            uint32_t at = kk;                                                                                      \
+            for (;;) {                              /* the literal itself (d_), then the rest of the tile in the recording form */ \
+                n_ev++;                                                                                            \
+                const uint32_t r = slow_step(d_);                                                                  \
+                wrl(ranks, 0x80000000u | r, at);                                                                   \
+                if (at == 63u) break;                                                                              \
+                const uint32_t ent = at + 1;                                                                       \
+                ZLNG_MTF_TILE_RE(PKIN, ent);                                                                       \
+                if (lv_ == 0) break;                                                                               \
+                at = lv_ - 1;                                                                                      \
+            }                                                                                                      \
+            const uint32_t rk = (ranks & 0x80000000u) ? (ranks & 0xFFu) : (uint32_t)__builtin_ctz(ranks | 0x40000000u); \
+            if (lane >= kk) run[(BASE) + lane] = (uint8_t)rk;      /* lanes below kk keep their literal for the replay */ \
             if (lane == 0) tile_kk[(BASE) >> 6] = (uint8_t)kk;                                                     \
         }                                                                                                          \
     }
@@ -466,6 +598,7 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
 #undef RANKSTORE
 #undef ZLNG_MTF_FULL_TILE
     st[lane] = (uint8_t)t0; st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
+    if (a.dbg && lane == 0) { a.dbg[ctx] = __builtin_readcyclecounter() - tstart; a.dbg[256 + ctx] = n_ev; }
 }
 
 // ------------------------------------------------------------------------------ K2d'
