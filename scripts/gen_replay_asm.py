@@ -482,13 +482,18 @@ def generate():
     emit("END_%=:")
 
 
-def main():
+def render():
     generate()
     body = " \\\n".join('    "%s\\n"' % ln for ln in lines)
+    return ("// replay_loop.h -- GENERATED by scripts/gen_replay_asm.py (do not edit; edit the generator and run it).\n"
+            "// The software-pipelined token loop of k_rolz_replay (decode.hip), which documents the registers and the LDS layout.\n"
+            "#pragma once\n#define ZLNG_REPLAY_LOOP_ASM \\\n" + body + "\n")
+
+
+def main():
+    text = render()
     with open(OUT, "w") as f:
-        f.write("// replay_loop.h -- GENERATED by scripts/gen_replay_asm.py (do not edit; edit the generator and run it).\n"
-                "// The software-pipelined token loop of k_rolz_replay (decode.hip), which documents the registers and the LDS layout.\n"
-                "#pragma once\n#define ZLNG_REPLAY_LOOP_ASM \\\n" + body + "\n")
+        f.write(text)
     print("wrote", OUT, len(lines), "lines")
 
 

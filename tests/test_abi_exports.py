@@ -84,3 +84,19 @@ def test_every_environment_variable_read_by_the_sources_is_documented():
     docs = open(os.path.join(root, "include", "zlng.h")).read() + open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(v for v in used if v not in docs)
     assert not missing, missing
+
+
+def test_generated_replay_loop_header_is_current():
+    """csrc/replay_loop.h is generated (scripts/gen_replay_asm.py); the committed file must be what the generator writes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_replay_asm", os.path.join(ROOT, "scripts", "gen_replay_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    old = os.environ.pop("REPLAY_DROP", None)
+    try:
+        spec.loader.exec_module(mod)
+        text = mod.render()
+    finally:
+        if old is not None:
+            os.environ["REPLAY_DROP"] = old
+    with open(os.path.join(ROOT, "libzling_amd", "csrc", "replay_loop.h")) as f:
+        assert f.read() == text
