@@ -249,76 +249,17 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
 //         t0[rank-1] = t0[rank];  t0[rank] = t0[next];  t0[next] = c
 //     (next <= rank - 2 from rank 21 on, so t0[next] is untouched); mtfnext = (rank * 62263) >> 16 below 128.
 //     The rank is recorded as 0x80000000 | rank.
-//   rank >= 64 (c not in t0, nothing was changed): leave the statement with lv = 1; lane K of ranks holds 0.
+//   rank >= 64 (c not in t0, nothing was changed): leave the statement with lv = K + 1; lane K of ranks holds 0.
 // v_readlane / v_writelane lane selects come from SALU results or M0 (no wait states owed); both reads of t0
 // happen before its first write (next <= rank - 2, so the three lanes are distinct).  VCC is free here: step KN
 // recomputes it.  SCC is set again before re-entering step KN, whose late branch is evaluated a second time.
-#define ZLNG_MTF_G_SLOW(PK, B, K, KN)                                                                           \
-    "1" #K ":\n\t"                                                                                              \
-    "v_cmp_eq_u32_sdwa vcc, %[" #PK "], %[t0] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
-    "s_bfe_u32 %[d], %[" #PK "], (8 * " #B ") | (8 << 16)\n\t"                                                  \
-    "s_cbranch_vccz 8f\n\t"                                                                                     \
-    "s_ff1_i32_b64 %[nx], vcc\n\t"                                                                              \
-    "s_add_u32 %[i], %[nx], 1\n\t"                                                                              \
-    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
-    "s_mul_i32 %[nx], %[i], 0xf337\n\t"                                                                         \
-    "v_readlane_b32 %[da], %[t0], %[i]\n\t"                                                                     \
-    "s_lshr_b32 %[nx], %[nx], 16\n\t"                                                                           \
-    "v_readlane_b32 %[db], %[t0], %[nx]\n\t"                                                                    \
-    "v_writelane_b32 %[t0], %[da], m0\n\t"                                                                      \
-    "s_mov_b32 m0, %[i]\n\t"                                                                                    \
-    "v_writelane_b32 %[t0], %[db], m0\n\t"                                                                      \
-    "s_mov_b32 m0, %[nx]\n\t"                                                                                   \
-    "v_writelane_b32 %[t0], %[d], m0\n\t"                                                                       \
-    "s_bitset1_b32 %[i], 31\n\t"                                                                                \
-    "v_writelane_b32 %[ranks], %[i], " #K "\n\t"                                                                \
-    "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
-    "s_branch 2" #KN "b\n\t"
+// (its code is ZLNG_MTF_R_SLOW below: the round-1 form of the whole tile, ZLNG_MTF_TILE, which started at step 0 only and loaded
+// the next tile itself, is gone -- only the re-entrant form is used.)
 // four steps = one literal register: Z = the step before A
 #define ZLNG_MTF_G_FAST(PK, Z, A, B, C, D)                                                                      \
     ZLNG_MTF_G_STEP(PK, 0, A, Z) ZLNG_MTF_G_STEP(PK, 1, B, A) ZLNG_MTF_G_STEP(PK, 2, C, B) ZLNG_MTF_G_STEP(PK, 3, D, C)
-#define ZLNG_MTF_G_COLD(PK, A, B, C, D, N)                                                                      \
-    ZLNG_MTF_G_SLOW(PK, 0, A, B) ZLNG_MTF_G_SLOW(PK, 1, B, C) ZLNG_MTF_G_SLOW(PK, 2, C, D) ZLNG_MTF_G_SLOW(PK, 3, D, N)
 
-// A whole 64-literal tile.  Labels: 2K = top of step K, 1K = out-of-line part of step K, 264 = after step 63,
-// 8 = leave, 9 = end.  Step 0 has no predecessor: SCC is set on entry and its branch (to any label) is never taken.
-#define ZLNG_MTF_TILE()                                                                                         \
-    asm volatile(                                                                                               \
-        "s_load_dwordx16 %[nxt], %[ptr], 0x40\n\t"                                                              \
-        "s_cmp_eq_u32 0, 0\n\t"                                                                                 \
-        ZLNG_MTF_G_FAST(p0, 19, 0, 1, 2, 3)      ZLNG_MTF_G_FAST(p1, 3, 4, 5, 6, 7)                             \
-        ZLNG_MTF_G_FAST(p2, 7, 8, 9, 10, 11)     ZLNG_MTF_G_FAST(p3, 11, 12, 13, 14, 15)                        \
-        ZLNG_MTF_G_FAST(p4, 15, 16, 17, 18, 19)  ZLNG_MTF_G_FAST(p5, 19, 20, 21, 22, 23)                        \
-        ZLNG_MTF_G_FAST(p6, 23, 24, 25, 26, 27)  ZLNG_MTF_G_FAST(p7, 27, 28, 29, 30, 31)                        \
-        ZLNG_MTF_G_FAST(p8, 31, 32, 33, 34, 35)  ZLNG_MTF_G_FAST(p9, 35, 36, 37, 38, 39)                        \
-        ZLNG_MTF_G_FAST(p10, 39, 40, 41, 42, 43) ZLNG_MTF_G_FAST(p11, 43, 44, 45, 46, 47)                       \
-        ZLNG_MTF_G_FAST(p12, 47, 48, 49, 50, 51) ZLNG_MTF_G_FAST(p13, 51, 52, 53, 54, 55)                       \
-        ZLNG_MTF_G_FAST(p14, 55, 56, 57, 58, 59) ZLNG_MTF_G_FAST(p15, 59, 60, 61, 62, 63)                       \
-        "264:\n\t"                                                                                              \
-        "s_cbranch_scc0 163f\n\t"                                                                               \
-        "s_mov_b32 %[lv], 0\n\t"                                                                                \
-        "s_branch 9f\n\t"                                                                                       \
-        ZLNG_MTF_G_COLD(p0, 0, 1, 2, 3, 4)       ZLNG_MTF_G_COLD(p1, 4, 5, 6, 7, 8)                             \
-        ZLNG_MTF_G_COLD(p2, 8, 9, 10, 11, 12)    ZLNG_MTF_G_COLD(p3, 12, 13, 14, 15, 16)                        \
-        ZLNG_MTF_G_COLD(p4, 16, 17, 18, 19, 20)  ZLNG_MTF_G_COLD(p5, 20, 21, 22, 23, 24)                        \
-        ZLNG_MTF_G_COLD(p6, 24, 25, 26, 27, 28)  ZLNG_MTF_G_COLD(p7, 28, 29, 30, 31, 32)                        \
-        ZLNG_MTF_G_COLD(p8, 32, 33, 34, 35, 36)  ZLNG_MTF_G_COLD(p9, 36, 37, 38, 39, 40)                        \
-        ZLNG_MTF_G_COLD(p10, 40, 41, 42, 43, 44) ZLNG_MTF_G_COLD(p11, 44, 45, 46, 47, 48)                       \
-        ZLNG_MTF_G_COLD(p12, 48, 49, 50, 51, 52) ZLNG_MTF_G_COLD(p13, 52, 53, 54, 55, 56)                       \
-        ZLNG_MTF_G_COLD(p14, 56, 57, 58, 59, 60) ZLNG_MTF_G_COLD(p15, 60, 61, 62, 63, 64)                       \
-        "8:\n\t"                                                                                                \
-        "s_mov_b32 %[lv], 1\n\t"                                                                                \
-        "9:\n\t"                                                                                                \
-        "s_waitcnt lgkmcnt(0)"                                                                                  \
-        : [t0] "+v"(t0), [up] "+v"(up), [ranks] "+v"(ranks), [m1] "=&s"(m1_), [i] "=&s"(i_), [nx] "=&s"(nx_),   \
-          [d] "=&s"(d_), [da] "=&s"(da_), [db] "=&s"(db_), [lv] "=&s"(lv_), [nxt] "=&s"(nxt)                    \
-        : [ptr] "s"(tile_ptr), [p0] "s"(pk[0]), [p1] "s"(pk[1]), [p2] "s"(pk[2]), [p3] "s"(pk[3]),              \
-          [p4] "s"(pk[4]), [p5] "s"(pk[5]), [p6] "s"(pk[6]), [p7] "s"(pk[7]), [p8] "s"(pk[8]), [p9] "s"(pk[9]), \
-          [p10] "s"(pk[10]), [p11] "s"(pk[11]), [p12] "s"(pk[12]), [p13] "s"(pk[13]), [p14] "s"(pk[14]),        \
-          [p15] "s"(pk[15])                                                                                     \
-        : "vcc", "scc", "s98", "s99", "m0")
-
-// ---- re-entrant recording tile: ZLNG_MTF_TILE's steps, entered at step `ent` through a table of branches, without the
+// ---- re-entrant recording tile: the recording steps (ZLNG_MTF_G_STEP), entered at step `ent` through a table of branches, without the
 // next tile's load.  It is what finishes a tile of the chain after a literal of rank >= 64 made the state-only form below
 // leave: the literal is dealt with outside (slow_step), then the rest of the tile runs here at the speed of the recording
 // step instead of the compiler-scheduled ZLNG_MTF_STEP loop (source text: 85 % of the blank's tiles meet such a literal,
@@ -543,7 +484,7 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
         return i;
     };
 
-    uint32_t up = 0xFFFFFFFFu;                                         // ZLNG_MTF_TILE: t0 shifted down one lane
+    uint32_t up = 0xFFFFFFFFu;                                         // the tile statements' scratch: t0 shifted down one lane
     uint8_t* run = a.lit_byte + a.ctx_off[ctx];                       // 64-byte aligned (k_ctx_offsets)
     uint8_t* snap = a.snap + a.ctx_off[ctx];
     uint8_t* tile_kk = a.tile_kk + (a.ctx_off[ctx] >> 6);
@@ -561,7 +502,7 @@ __global__ __launch_bounds__(64) void k_mtf_dense(MtfArgs a) {
         snap[(BASE) + lane] = (uint8_t)t0;          /* table front at the start of the tile, for k_mtf_replay */   \
         ZLNG_MTF_TILE_S(PKIN, NXTOUT);                                                                             \
         if (__builtin_expect(lv_ != 0, 0)) {        /* literal lv_ - 1 has rank >= 64: the statement stopped there */ \
-            uint32_t ranks = 0;                     /* one-hot word or 0x80000000 | rank per lane, as ZLNG_MTF_TILE records */ \
+            uint32_t ranks = 0;                     /* one-hot word or 0x80000000 | rank per lane, as the recording steps leave it */     \
             const uint32_t kk = lv_ - 1;                                                                           \
             uint32_t at = kk;                                                                                      \
             for (;;) {                              /* the literal itself (d_), then the rest of the tile in the recording form */ \
