@@ -52,16 +52,21 @@ template <class T, uint32_t kStride = (uint32_t)sizeof(T)> struct BktField {
     uint8_t* d; uint32_t o;
     __device__ __forceinline__ T& operator[](uint32_t i) const { return *reinterpret_cast<T*>(d + (o + kStride * i)); }
 };
+// Both forms of a bucket keep a ring slot in 8 bytes at b + 8 i (zlng_common.h):
+//   wide   {own word, copy of the linked slot's word}, the link itself (suffix) in its own plane behind the slots;
+//   paired {own word, link (u16), unused}: a chain hop of the generic walk reads a node's word AND its link from one
+//          8-byte record -- one memory line per node instead of two (round 3; the "compact" form it replaces kept the links in a
+//          second plane: with >= 128 blocks in flight the e1-e4 parse is bound by the lines it touches, profiles/r03_h).
 template <bool kWide> struct BucketT {
-    static constexpr uint32_t kSlot = kWide ? 8u : 4u;
+    static constexpr uint32_t kSlot = 8u;
     BktField<uint32_t, kSlot> offset;          // a slot's own word
     BktField<unsigned long long, 8> slot;      // wide form only: own word + the linked slot's word as of the time the link was made
-    BktField<uint16_t> suffix; BktField<uint16_t> hash;
+    BktField<uint16_t, kWide ? 2u : 8u> suffix; BktField<uint16_t> hash;
     __device__ __forceinline__ BucketT(uint8_t* dict, uint32_t ctx) {
         const uint32_t b = ctx * kBktBytes;
         offset = {dict, b};
         slot   = {dict, b};
-        suffix = {dict, b + kSlot * kRing};
+        suffix = {dict, kWide ? b + kSlot * kRing : b + 4u};
         hash   = {dict, b + kSlot * kRing + 2u * kRing};
     }
 };

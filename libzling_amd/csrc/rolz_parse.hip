@@ -18,14 +18,15 @@ namespace zlng {
 // Reset(): offset = 0, suffix = 0xFFFF, hash = 0xFFFF for every bucket (src/libzling_lz.cpp:197-209).
 // Pure streaming fill: 14.7 MB per block, 16 B per lane per store.  `slot_bytes`: size of the slot plane in the
 // form the following parse uses (zlng_common.h); what lies behind the planes of the compact form is filled too.
-__global__ __launch_bounds__(256) void k_dict_reset(uint8_t* dict, uint32_t nblocks, uint32_t slot_bytes) {
+// slots: words 0 (wide: {own, link's copy}; paired: own word 0, link 65535 in the upper half); link plane and hash heads: 65535
+__global__ __launch_bounds__(256) void k_dict_reset(uint8_t* dict, uint32_t nblocks, uint32_t wide) {
     const size_t vec_per_bkt = kBktBytes / 16;                       // 3584 uint4 per bucket
     const size_t total = (size_t)nblocks * 256 * vec_per_bkt;
     uint4* d = reinterpret_cast<uint4*>(dict);
+    const uint32_t hi = wide ? 0u : 0xFFFFFFFFu;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         uint32_t within = (uint32_t)(i % vec_per_bkt) * 16;
-        uint32_t v = within < slot_bytes ? 0u : 0xFFFFFFFFu;
-        d[i] = make_uint4(v, v, v, v);
+        d[i] = within < 8u * (uint32_t)kRing ? make_uint4(0u, hi, 0u, hi) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     }
 }
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64) void k_rolz_parse_serial(ParseArgs a) {
 }
 
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide) {
-    hipLaunchKernelGGL(k_dict_reset, dim3(2048), dim3(256), 0, s, dict, nblocks, (wide ? 8u : 4u) * (uint32_t)kRing);
+    hipLaunchKernelGGL(k_dict_reset, dim3(2048), dim3(256), 0, s, dict, nblocks, wide ? 1u : 0u);
 }
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_rolz_parse_serial, dim3(nblocks - a.blk0), dim3(64), 0, s, a);

@@ -31,9 +31,8 @@ constexpr int kMaxSub = 80;
 // ---- HBM layout of one context's dictionary: 256 buckets x 57,344 B ------------------
 // (the reference's ZlingEncodeBucket, src/libzling_lz.h:98-103, re-laid as three planes; `head` lives in LDS
 //  during a parse.)  Two forms of the slot plane, chosen per parse kernel (rolz_dev.h BucketT):
-//   compact  u32 slot = pos | hash_check << 24; planes at 0 / 16 KiB / 24 KiB, 40,960 B of the bucket used
-//            (serial and pipelined parsers, and the wave parser on a context whose level is not 0: its generic
-//            speculation walks long chains and wants the plane dense);
+//   paired   8-byte slot = own word (pos | hash_check << 24) + the slot's link (u16): the generic chain walk of levels 1-4
+//            (and the serial / pipelined parsers) reads a node's word and its successor's index from one record;
 //   wide     8-byte slot = own word + a copy of the word of the slot it links to, taken when the link was made:
 //            the level-0 wave parser reads a chain's second node without a dependent load (`speculate_l0w`
 //            says when the copy is what the reference would read and what follows when it is not).
