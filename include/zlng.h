@@ -156,7 +156,7 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
 
 /* Environment read when a context is created (testing / measurement aids; none of them changes the bytes produced):
  *   ZLNG_PARSER=wave|serial|pipe  cross-check forms of the block parser (default: the workgroup-wide window parser, rolz_wg.hip;
- *                                 wave = the one-wavefront parser of rounds 1-2); ZLNG_WG_WAVES=2|4|8: wavefronts per block of the default, ZLNG_WG_COMPACT=1: its compact slot plane, ZLNG_WG_HOT=1: the hottest context's bucket mirrored in LDS
+ *                                 wave = the one-wavefront parser of rounds 1-2); ZLNG_WG_WAVES=2|4|8: wavefronts per block of the default, ZLNG_WG_COMPACT=1: the paired slot records of levels 1-4 at level 0 too (default there: the wide form), ZLNG_WG_HOT=1: the hottest context's bucket mirrored in LDS
  *   ZLNG_MTF=front                the front / back form of the rank chain (exact, measured slower; default: k_mtf_dense)
  *   ZLNG_DEC=plain                the compiler-scheduled replay loop of the decoder (k_rolz_decode; default: the generated,
  *                                 software-pipelined k_rolz_replay, scripts/gen_replay_asm.py)

@@ -484,7 +484,7 @@ __device__ __forceinline__ void speculate_l0w(Spec& S, uint8_t* dict, const uint
         q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
         ql = ld128u(buf + (hasl ? (lov1 & 0xFFFFFF) : (uint32_t)pos));
     } else {
-        // compact plane: node 1's word is a dependent load (round trip 3, beside node 0's compare block and the
+        // paired form (no copy of the link's word): node 1's word is a dependent load (round trip 3, beside node 0's compare block and the
         // probe's source bytes), its compare block a fourth round trip
         q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
         nov = B.offset[nx & (kRing - 1)];

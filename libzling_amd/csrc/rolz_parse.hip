@@ -16,8 +16,8 @@ namespace zlng {
 
 // ------------------------------------------------------------------------------ K0
 // Reset(): offset = 0, suffix = 0xFFFF, hash = 0xFFFF for every bucket (src/libzling_lz.cpp:197-209).
-// Pure streaming fill: 14.7 MB per block, 16 B per lane per store.  `slot_bytes`: size of the slot plane in the
-// form the following parse uses (zlng_common.h); what lies behind the planes of the compact form is filled too.
+// Pure streaming fill: 14.7 MB per block, 16 B per lane per store.  `wide`: the form of the slots the following parse uses
+// (zlng_common.h).
 // slots: words 0 (wide: {own, link's copy}; paired: own word 0, link 65535 in the upper half); link plane and hash heads: 65535
 __global__ __launch_bounds__(256) void k_dict_reset(uint8_t* dict, uint32_t nblocks, uint32_t wide) {
     const size_t vec_per_bkt = kBktBytes / 16;                       // 3584 uint4 per bucket
