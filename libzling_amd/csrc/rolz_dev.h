@@ -69,6 +69,12 @@ template <bool kWide> struct BucketT {
         suffix = {dict, kWide ? b + kSlot * kRing : b + 4u};
         hash   = {dict, b + kSlot * kRing + 2u * kRing};
     }
+    // a node's word and its link: ONE 8-byte load in the paired form (a scattered load instruction costs the compute unit's one
+    // address path ~64 cycles per wavefront whatever its width, and a chain hop of the generic walk is bound by just that)
+    __device__ __forceinline__ void node(uint32_t i, uint32_t& word, uint32_t& link) const {
+        if (kWide) { word = offset[i]; link = suffix[i]; }
+        else { const unsigned long long r = slot[i]; word = (uint32_t)r; link = (uint32_t)(r >> 32) & 0xFFFFu; }
+    }
 };
 using Bucket = BucketT<false>;
 
@@ -263,8 +269,8 @@ __device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, i
         const uint32_t off = lov & 0xFFFFFF;
         const uint32_t srcw = ld32u(buf + (active ? off + m : (uint32_t)ppos));
         const uint32_t nn = lsfx;
-        const uint32_t nov = B.offset[nn & (kRing - 1)];
-        const uint32_t nsfx = B.suffix[nn & (kRing - 1)];
+        uint32_t nov, nsfx;
+        B.node(nn & (kRing - 1), nov, nsfx);
         if (active && probe == srcw) { veto = true; vpos = (uint32_t)i; active = false; }
         active = active && nn != 65535u;
         if (active) ld = min(ld, ring_dist(nn, lhead));
@@ -287,11 +293,12 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     const uint32_t node0 = B.hash[hc];
     const uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
     const uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
-    uint32_t ov = B.offset[node0 & (kRing - 1)];
-    uint32_t nx = B.suffix[node0 & (kRing - 1)];
+    uint32_t ov, nx;
+    B.node(node0 & (kRing - 1), ov, nx);
     S.ov0 = ov;                                      // the inserting lane stores it as its link's copy
-    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)], lov2 = B2.offset[ln2 & (kRing - 1)];
-    const uint32_t lsf1 = B1.suffix[ln1 & (kRing - 1)], lsf2 = B2.suffix[ln2 & (kRing - 1)];
+    uint32_t lov1, lov2, lsf1, lsf2;
+    B1.node(ln1 & (kRing - 1), lov1, lsf1);
+    B2.node(ln2 & (kRing - 1), lov2, lsf2);
 
     uint32_t maxlen = kMatchMin - 1, maxnode = 0, node = node0, dmin = kRing - 1;
     bool active = node0 != 65535u;
@@ -302,8 +309,8 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     uint32_t off = ov & 0xFFFFFF;
     bool cmp = active && (ov >> 24) == chk;
     Quad qb = ld128u(buf + (cmp ? off : (uint32_t)pos));
-    uint32_t nov = B.offset[nx & (kRing - 1)];
-    uint32_t nnx = B.suffix[nx & (kRing - 1)];
+    uint32_t nov, nnx;
+    B.node(nx & (kRing - 1), nov, nnx);
     uint32_t pre1 = 0xFFFFFFFFu, pre2 = 0xFFFFFFFFu;                       // (unset: the walk ended before that many nodes)
     for (int i = 0; i < cfg.depth && __any(active); i++) {                 // src/libzling_lz.cpp:240-267
         if (i == cfg.depth - 1) pre1 = maxlen | maxnode << kSpNodeShift;       // the first i nodes are in
@@ -313,8 +320,8 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
         const bool more = active && nx != 65535u && !(off <= off_n);
         const bool cmp_n = more && (nov >> 24) == chk;
         const Quad qb_n = ld128u(buf + (cmp_n ? off_n : (uint32_t)pos));
-        const uint32_t nov_n = B.offset[nnx & (kRing - 1)];
-        const uint32_t nnx_n = B.suffix[nnx & (kRing - 1)];
+        uint32_t nov_n, nnx_n;
+        B.node(nnx & (kRing - 1), nov_n, nnx_n);
         uint32_t len = cmp ? lcp16(qa, qb) : 0u;
         const bool lng = cmp && len == 16u;
         if (__any(lng)) { const uint32_t t = lcp_tail(buf + pos, buf + off, lng); len = lng ? t : len; }
