@@ -267,6 +267,9 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     uint32_t nt = 0;
     int q = 0, nsub = 0;
     bool overflow = false;
+    int pf_P = -1;                                   // start of the window whose text pf_* hold (-1: none)
+    uint32_t pf_wraw = 0, pf_t16 = 0;
+    Quad pf_q = {0, 0, 0, 0};
     u64 c_p1 = 0, c_tab = 0, c_it = 0, c_com = 0, c_ser = 0, n_round = 0, n_iter = 0, n_ser = 0, n_hardr = 0, n_pos = 0, n_cutr = 0;
     u64 c_dep = 0, c_ev = 0, c_lim = 0, c_x1 = 0, c_x2 = 0, c_x3 = 0;
     const bool prof = kProf && a.dbg != nullptr;
@@ -358,9 +361,16 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
             const bool canm = pos + kSentinel < ilen;
             // lanes past the end of the block read the text of the round's first position instead (their results are never used)
             const uint32_t upos = live ? (uint32_t)pos : (uint32_t)P;
-            const uint32_t wraw = ld32u(buf + (upos >= 4u ? upos - 4u : 0u));
-            const Quad qtext = ld128u(buf + upos);
-            const uint32_t t16 = ld32u(buf + (upos + 16u));
+            // the window's text: asked for at the end of the previous round, in front of that round's last barrier, so that the
+            // round trip runs beside the drain of the commit's stores instead of behind it
+            uint32_t wraw, t16;
+            Quad qtext;
+            if (P == pf_P) { wraw = pf_wraw; qtext = pf_q; t16 = pf_t16; }
+            else {
+                wraw = ld32u(buf + (upos >= 4u ? upos - 4u : 0u));
+                qtext = ld128u(buf + upos);
+                t16 = ld32u(buf + (upos + 16u));
+            }
             const uint32_t wp = upos >= 4u ? wraw : wraw << ((8u * (4u - upos)) & 31u);
             const uint32_t w4 = qtext.a;
             const uint32_t ctx = wp >> 24;
@@ -808,6 +818,14 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
             // is a walk of up to 16 dependent round trips by one wavefront (9-16 K cycles), and the next round, which starts AT the
             // token, evaluates it as its lane 0 against the dictionary as it then is -- exact unless it conflicts with its own insert.
             serial_next = limit_hard && (level0 || limit == 0 || a.min_restart < 0);
+            if (!serial_next && q < ilen) {                          // the next round starts at q: its text
+                const int np = q + tid;
+                const uint32_t nu = np < ilen ? (uint32_t)np : (uint32_t)q;
+                pf_wraw = ld32u(buf + (nu >= 4u ? nu - 4u : 0u));
+                pf_q = ld128u(buf + nu);
+                pf_t16 = ld32u(buf + (nu + 16u));
+                pf_P = q;
+            } else pf_P = -1;
             if (limit == 0 && !limit_hard) overflow = true;         // cannot happen: a round commits a token or names a hard one
             // my bits of the last iteration's buffer
             if (dep_prev) {
