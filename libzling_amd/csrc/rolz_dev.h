@@ -281,18 +281,29 @@ __device__ __forceinline__ void lazy_spec_u(uint8_t* dict, const uint8_t* buf, i
 
 // head0 / lhead1 / lhead2: ring heads of the position's bucket and of the two probe buckets as the caller read them;
 // risk_dist: a probe that visited a node within this many slots ahead of its bucket's head gets the kSpRisk flag.
-__device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t lhead2,
-                                          uint32_t risk_dist, int pos,
-                                          const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
+// speculate_heads: the three hash heads of a position (round trip 1 of speculate).  A caller with work that does not depend on the
+// dictionary (the wg parser's row claims) asks for them first and hands them to speculate_from.
+__device__ __forceinline__ void speculate_heads(uint8_t* dict, const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc,
+                                                uint32_t& node0, uint32_t& ln1, uint32_t& ln2) {
+    const uint32_t w4 = qa.a;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
+    Bucket B(dict, ctx), B1(dict, w4 & 0xFF), B2(dict, (w4 >> 8) & 0xFF);
+    node0 = B.hash[hc];
+    ln1 = cfg.lazy1 > 0 ? (uint32_t)B1.hash[hh1] : 65535u;
+    ln2 = cfg.lazy2 > 0 ? (uint32_t)B2.hash[hh2] : 65535u;
+}
+
+__device__ __forceinline__ void speculate_from(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t lhead2,
+                                               uint32_t risk_dist, int pos,
+                                               const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk,
+                                               const uint32_t node0, const uint32_t ln1, const uint32_t ln2) {
     const uint32_t w4 = qa.a;                        // qa: bytes pos .. pos+15, loaded by the caller (pos+275 < ilen)
     const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
     const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
     const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
     const uint32_t hh2 = hash_of(w4 >> 16 | qa.b << 16) % kHashSlots;
     Bucket B(dict, ctx), B1(dict, lctx1), B2(dict, lctx2);
-    const uint32_t node0 = B.hash[hc];
-    const uint32_t ln1 = want1 ? (uint32_t)B1.hash[hh1] : 65535u;
-    const uint32_t ln2 = want2 ? (uint32_t)B2.hash[hh2] : 65535u;
     uint32_t ov, nx;
     B.node(node0 & (kRing - 1), ov, nx);
     S.ov0 = ov;                                      // the inserting lane stores it as its link's copy
@@ -351,6 +362,14 @@ __device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t*
     S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = key_ix(lctx2, hh2); S.lctx1 = lctx1; S.lctx2 = lctx2;
     S.ld1 = ld1; S.ld2 = ld2;
     S.lz1 = lz && want1; S.lz2 = lz && want2;
+}
+
+__device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t lhead2,
+                                          uint32_t risk_dist, int pos,
+                                          const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
+    uint32_t node0, ln1, ln2;
+    speculate_heads(dict, cfg, qa, ctx, hc, node0, ln1, ln2);
+    speculate_from(S, dict, buf, head0, lhead1, lhead2, risk_dist, pos, cfg, qa, ctx, hc, chk, node0, ln1, ln2);
 }
 
 // Level-0 form of speculate() (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130): the same

@@ -68,10 +68,21 @@ struct WSpec {
 // kHot: the bucket of ONE context (`hotctx`, the block's most frequent byte) is mirrored in LDS (`hot`: the wide layout of
 // zlng_common.h, 57,344 B, written through by every insert); lanes of that context -- 40 % of a text's positions -- take their hash
 // head, ring slot and link from LDS, and their global loads are pointed at one shared line instead of 64 scattered ones.
+// round trip 1 of speculate_l0t, both hash heads: asked for by the caller ahead of work that does not depend on them (the row claims)
+template <bool kWide, bool kHot>
+__device__ __forceinline__ void speculate_l0t_heads(uint8_t* dict, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t hotctx, uint32_t& node0, uint32_t& ln1) {
+    const uint32_t w4 = qa.a;
+    const uint32_t lctx1 = w4 & 0xFF;
+    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
+    BucketT<kWide> B(dict, ctx), B1(dict, lctx1);
+    node0 = B.hash[(kHot && ctx == hotctx) ? 0u : hc];
+    ln1 = B1.hash[(kHot && lctx1 == hotctx) ? 0u : hh1];
+}
+
 template <bool kWide, bool kHot>
 __device__ __forceinline__ void speculate_l0t(WSpec& W, Quad& ql_out, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t pos,
                                               const Quad qa, uint32_t t16, uint32_t ctx, uint32_t hc, uint32_t chk,
-                                              const uint8_t* hot, uint32_t hotctx) {
+                                              const uint8_t* hot, uint32_t hotctx, uint32_t node0, uint32_t ln1) {
     const uint32_t w4 = qa.a;
     const uint32_t lctx1 = w4 & 0xFF;
     const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
@@ -80,9 +91,6 @@ __device__ __forceinline__ void speculate_l0t(WSpec& W, Quad& ql_out, uint8_t* d
     const uint16_t* hot_hash = reinterpret_cast<const uint16_t*>(hot + 8u * kRing + 2u * kRing);
     const uint16_t* hot_sfx = reinterpret_cast<const uint16_t*>(hot + 8u * kRing);
     const u64* hot_slot = reinterpret_cast<const u64*>(hot);
-    // round trip 1: both hash heads
-    uint32_t node0 = B.hash[h0 ? 0u : hc];
-    uint32_t ln1 = B1.hash[h1 ? 0u : hh1];
     if (kHot) { const uint32_t a0 = hot_hash[h0 ? hc : 0u], a1 = hot_hash[h1 ? hh1 : 0u]; node0 = h0 ? a0 : node0; ln1 = h1 ? a1 : ln1; }
     const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
     // round trip 2: node 0's slot (wide: own word + its link's), its link, the probe node's word
@@ -383,36 +391,14 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
 
             WSpec W;
             const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
+            const uint32_t lkey1 = lctx1 << 13 | (hash_of(w4 >> 8 | qtext.b << 24) % kHashSlots);
+            const uint32_t lkey2 = lctx2 << 13 | (hash_of(w4 >> 16 | qtext.b << 16) % kHashSlots);
             Quad ql = {0, 0, 0, 0};
-            if (level0) {
-                speculate_l0t<kWide, kHot>(W, ql, dict, buf, heads[ctx], heads[lctx1], upos, qtext, t16, ctx, hc, chk, hot, hotctx);
-            } else {
-                Spec S1;
-                S1.sp = kMatchMin - 1; S1.node0 = 65535; S1.head0 = 0; S1.dmin = kRing - 1;
-                S1.lkix1 = S1.lkix2 = S1.lctx1 = S1.lctx2 = 0; S1.lz1 = S1.lz2 = false; S1.ld1 = S1.ld2 = kRing - 1; S1.ov0 = 0;
-                S1.pre1 = S1.pre2 = kMatchMin - 1; S1.vpos1 = S1.vpos2 = 0;
-                if (canm) speculate(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk);
-                W.len = S1.sp & kSpLenMask; W.node = (S1.sp >> kSpNodeShift) & (kRing - 1);
-                W.node0 = S1.node0; W.ov0 = S1.ov0; W.dmin = S1.dmin; W.d0 = W.d1 = S1.dmin;
-                W.has0 = S1.node0 != 65535u; W.has1 = false; W.len0 = 0;
-                W.veto1 = (S1.sp & kSpVeto1) != 0; W.veto2 = (S1.sp & kSpVeto2) != 0; W.lz1 = S1.lz1; W.lz2 = S1.lz2;
-                W.lkey1 = lctx1 << 13 | (hash_of(w4 >> 8 | qtext.b << 24) % kHashSlots);
-                W.lkey2 = lctx2 << 13 | (hash_of(w4 >> 16 | qtext.b << 16) % kHashSlots);
-                W.ld1 = S1.ld1; W.ld2 = S1.ld2; W.lsrc1 = 0;
-                W.pre1 = S1.pre1; W.pre2 = S1.pre2; W.vpos1 = S1.vpos1; W.vpos2 = S1.vpos2;
-            }
-            const uint32_t head0 = heads[ctx];
-            const uint32_t m0c = mru[ctx], m0e = mru[ek];           // MRU slots of my check key / my event key at the start of the round
-            // speculative token of this lane
-            const bool sp_veto = (want1 && W.veto1) || (want2 && W.veto2);
-            const bool sp_match = canm && W.len >= (uint32_t)kMatchMin && !(W.len < (uint32_t)kLazyLimit && sp_veto);
-            uint32_t ty = sp_match ? kTyMatch : kTyLit;            // token kind / length / match of this lane under the current S
-            uint32_t tlen = sp_match ? W.len : 1u;
-            uint32_t mlen = W.len, mnode = W.node;                  // mnode: ring slot, or 0x10000 | rank for a token of this round
-            int link = -1;                                          // rank of my in-slot predecessor among the tokens of this round (-1: the snapshot's head)
-            uint32_t link_chk = 0, link_lane = 0;
-            if (prof) { t1 = __builtin_readcyclecounter(); mk_last = t1; }
-
+            // round trip 1 (the hash heads) is requested first; the exact table rows of the round's keys -- LDS work that needs
+            // nothing from the dictionary -- are claimed while it is in flight
+            uint32_t hd0 = 65535u, hd1 = 65535u, hd2 = 65535u;
+            if (level0) speculate_l0t_heads<kWide, kHot>(dict, qtext, ctx, hc, hotctx, hd0, hd1);
+            else if (canm) speculate_heads(dict, cfg, qtext, ctx, hc, hd0, hd1, hd2);
             // ---------------- exact table rows of the round's keys (open addressing: a row belongs to ONE key)
             auto claim_row = [&](uint32_t k21, bool want) -> uint32_t {
                 uint32_t slot = wg_key_ix(k21), r = kWgRows;
@@ -428,8 +414,37 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
             };
             const uint32_t r_key = claim_row(key, canm);
             // the lazy probes' keys get rows too (one that no position of the window has stays empty)
-            const uint32_t r_lk1 = claim_row(W.lkey1, canm && want1);
-            const uint32_t r_lk2 = want2 ? claim_row(W.lkey2, canm) : (uint32_t)kWgRows;
+            const uint32_t r_lk1 = claim_row(lkey1, canm && want1);
+            const uint32_t r_lk2 = want2 ? claim_row(lkey2, canm) : (uint32_t)kWgRows;
+            if (level0) {
+                speculate_l0t<kWide, kHot>(W, ql, dict, buf, heads[ctx], heads[lctx1], upos, qtext, t16, ctx, hc, chk, hot, hotctx, hd0, hd1);
+            } else {
+                Spec S1;
+                S1.sp = kMatchMin - 1; S1.node0 = 65535; S1.head0 = 0; S1.dmin = kRing - 1;
+                S1.lkix1 = S1.lkix2 = S1.lctx1 = S1.lctx2 = 0; S1.lz1 = S1.lz2 = false; S1.ld1 = S1.ld2 = kRing - 1; S1.ov0 = 0;
+                S1.pre1 = S1.pre2 = kMatchMin - 1; S1.vpos1 = S1.vpos2 = 0;
+                if (canm) speculate_from(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk, hd0, hd1, hd2);
+                W.len = S1.sp & kSpLenMask; W.node = (S1.sp >> kSpNodeShift) & (kRing - 1);
+                W.node0 = S1.node0; W.ov0 = S1.ov0; W.dmin = S1.dmin; W.d0 = W.d1 = S1.dmin;
+                W.has0 = S1.node0 != 65535u; W.has1 = false; W.len0 = 0;
+                W.veto1 = (S1.sp & kSpVeto1) != 0; W.veto2 = (S1.sp & kSpVeto2) != 0; W.lz1 = S1.lz1; W.lz2 = S1.lz2;
+                W.lkey1 = lkey1;
+                W.lkey2 = lkey2;
+                W.ld1 = S1.ld1; W.ld2 = S1.ld2; W.lsrc1 = 0;
+                W.pre1 = S1.pre1; W.pre2 = S1.pre2; W.vpos1 = S1.vpos1; W.vpos2 = S1.vpos2;
+            }
+            const uint32_t head0 = heads[ctx];
+            const uint32_t m0c = mru[ctx], m0e = mru[ek];           // MRU slots of my check key / my event key at the start of the round
+            // speculative token of this lane
+            const bool sp_veto = (want1 && W.veto1) || (want2 && W.veto2);
+            const bool sp_match = canm && W.len >= (uint32_t)kMatchMin && !(W.len < (uint32_t)kLazyLimit && sp_veto);
+            uint32_t ty = sp_match ? kTyMatch : kTyLit;            // token kind / length / match of this lane under the current S
+            uint32_t tlen = sp_match ? W.len : 1u;
+            uint32_t mlen = W.len, mnode = W.node;                  // mnode: ring slot, or 0x10000 | rank for a token of this round
+            int link = -1;                                          // rank of my in-slot predecessor among the tokens of this round (-1: the snapshot's head)
+            uint32_t link_chk = 0, link_lane = 0;
+            if (prof) { t1 = __builtin_readcyclecounter(); mk_last = t1; }
+
             a_st[tid] = ty | tlen << 8;
             ZLNG_MK(0);
 
