@@ -431,3 +431,21 @@ def test_hybrid_host_rank_chains_through_group_and_range_encoder(zl, oracle, lev
     z = np.concatenate([out[a:a + k].cpu().numpy() for a, k in segs])
     assert z.size == ref.size and np.array_equal(z, ref)
     enc.close()
+
+
+def test_rank_chain_on_a_context_whose_ranks_stay_above_64(zl, oracle):
+    """The blank's context followed by 200 different bytes in rotation: every literal of that context has a rank >= 64, so every
+    tile of its chain leaves the state-only statement at its first literal and is finished by slow_step + the re-entrant
+    recording tile (mtf_rank.hip ZLNG_MTF_TILE_RE), entered at every step index over the run; mixed with text so that ranks
+    21..63 and the neighbour-swap path occur in the same tiles."""
+    from oracle_py import textgen
+    rng = np.random.Generator(np.random.PCG64(44))
+    n = 1_500_000
+    x = textgen(n, 12).copy()
+    pos = np.flatnonzero(x[:-1] == 32)                     # the byte behind every blank
+    sym = (np.arange(pos.size) * 7 % 200 + 33).astype(np.uint8)
+    keep = rng.random(pos.size) < 0.7                      # 70 % rotated (rank >= 64 mostly), the rest stay text
+    x[pos[keep] + 1] = sym[keep]
+    for lv in (0, 4):
+        z = zl.encode(x, lv)
+        assert np.array_equal(z, oracle.encode(x, lv)), lv
