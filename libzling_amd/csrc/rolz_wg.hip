@@ -370,7 +370,8 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
             // lanes past the end of the block read the text of the round's first position instead (their results are never used)
             const uint32_t upos = live ? (uint32_t)pos : (uint32_t)P;
             // the window's text: asked for at the end of the previous round, in front of that round's last barrier, so that the
-            // round trip runs beside the drain of the commit's stores instead of behind it
+            // round trip runs beside that barrier and this round's prologue instead of behind them (measured: asking even earlier,
+            // in front of the commit's stores, adds nothing -- the acknowledgements of the stores are not what the load waits for)
             uint32_t wraw, t16;
             Quad qtext;
             if (P == pf_P) { wraw = pf_wraw; qtext = pf_q; t16 = pf_t16; }
