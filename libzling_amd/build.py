@@ -85,11 +85,25 @@ def build_demo(force=False):
     return DEMO
 
 
+PROTOCOL_TEST = os.path.join(ROOT, "tests", "cxx", "protocol_test")
+
+
+def build_protocol_test(force=False):
+    """tests/cxx/protocol_test.cpp: a `-lzling` user with its own Inputter / Outputter / ActionHandler (tests/test_gpu_protocol.py)."""
+    src = os.path.join(ROOT, "tests", "cxx", "protocol_test.cpp")
+    if force or _stale(PROTOCOL_TEST, [src, SHIM_SO]):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-I", os.path.join(ROOT, "include", "libzling"),
+                               "-I", os.path.join(ROOT, "include"), "-o", PROTOCOL_TEST, src, "-L", PKG, "-lzling_amd", "-lzlng_hip",
+                               "-Wl,-rpath," + PKG, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    return PROTOCOL_TEST
+
+
 def build_all(force=False, verbose=False):
     build_textgen(force)
     build_hip(force, verbose)
     build_shim(force)
     build_demo(force)
+    build_protocol_test(force)
 
 
 if __name__ == "__main__":

@@ -75,9 +75,7 @@ struct zlng_ctx {
     uint8_t*  d_lit_byte = nullptr;
     uint8_t*  d_snap = nullptr;       // rank stage: table snapshots per 64-literal tile
     uint8_t*  d_tile_kk = nullptr;
-    uint8_t*  d_nfr = nullptr;        // rank stage, front / back form: ranks of the literals outside the table front
     int       dec_plain = 0;          // ZLNG_DEC=plain selects the compiler-scheduled replay loop (k_rolz_decode) instead of the hand-written one
-    int       mtf_front = 0;          // ZLNG_MTF=front selects the front / back form of the chain (k_mtf_front: exact, measured slower -- DESIGN.md)
     // Measured ALTERNATIVE, off by default (ZLNG_HOST_RANK_CONTEXTS=k): the k longest rank chains of a
     // call are walked by host threads instead of by k_mtf_dense, overlapped with the device's other chains.  The product
     // path is all-device; bench.py reports this mode as a separate, labelled line and never as `value`.
@@ -182,14 +180,14 @@ uint32_t* overflow_flag(zlng_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_s
 
 // (Re)allocate the pools whose size follows the token capacity per block.
 int alloc_token_pools(zlng_ctx* c, uint32_t tok_cap) {
-    for (void* p : {(void*)c->d_tok, (void*)c->d_tile_hist, (void*)c->d_lit_byte, (void*)c->d_snap, (void*)c->d_tile_kk, (void*)c->d_nfr}) if (p) hipFree(p);
-    c->d_tok = nullptr; c->d_tile_hist = nullptr; c->d_lit_byte = nullptr; c->d_snap = nullptr; c->d_tile_kk = nullptr; c->d_nfr = nullptr;
+    for (void* p : {(void*)c->d_tok, (void*)c->d_tile_hist, (void*)c->d_lit_byte, (void*)c->d_snap, (void*)c->d_tile_kk}) if (p) hipFree(p);
+    c->d_tok = nullptr; c->d_tile_hist = nullptr; c->d_lit_byte = nullptr; c->d_snap = nullptr; c->d_tile_kk = nullptr;
     const size_t nb = c->max_blocks;
     int rc;
     if ((rc = dev_alloc(c, &c->d_tok, nb * tok_cap)) || (rc = dev_alloc(c, &c->d_tile_hist, nb * (tok_cap / 4096) * 256)) ||
         (rc = dev_alloc(c, &c->d_lit_byte, nb * tok_cap + 256 * 64 + 128)) ||    // + run alignment + one tile of read-ahead
-        (rc = dev_alloc(c, &c->d_snap, nb * tok_cap + 256 * 64 + 128)) || (rc = dev_alloc(c, &c->d_tile_kk, (nb * tok_cap + 256 * 64) / 64 + 8)) ||
-        (rc = dev_alloc(c, &c->d_nfr, nb * tok_cap + 256 * 64 + 128)))
+        (rc = dev_alloc(c, &c->d_snap, 4 * (nb * tok_cap + 256 * 64) + 256)) ||   // one 256-byte table per tile of 64 literals
+        (rc = dev_alloc(c, &c->d_tile_kk, (nb * tok_cap + 256 * 64) / 64 + 8)))
         return rc;
     c->tok_cap = tok_cap;
     return ZLNG_OK;
@@ -201,8 +199,6 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
     static const int pf_env = getenv("ZLNG_PF_WAVES") ? atoi(getenv("ZLNG_PF_WAVES")) : -1;     // the wg parser: prefetch of the next window only on request (> 0): measured slower
     static const int pf_waves = pf_env < 0 ? 1 : std::min(3, std::max(1, pf_env));
-    static const int pipe_lead = getenv("ZLNG_PIPE_LEAD") ? atoi(getenv("ZLNG_PIPE_LEAD")) : 2;
-    static const int pipe_pf = getenv("ZLNG_PIPE_PF") ? atoi(getenv("ZLNG_PIPE_PF")) : 1;
     static const int settle_pf = getenv("ZLNG_SETTLE_PF") ? atoi(getenv("ZLNG_SETTLE_PF")) : 1;
     static const int lazy_fix = getenv("ZLNG_LAZY_FIX") ? atoi(getenv("ZLNG_LAZY_FIX")) : 1;
     ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
@@ -215,7 +211,6 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     timer_mark(c, "dict_reset");
     if (c->parser_kind == 3) { pa.pf_waves = pf_env > 0 ? 1 : 0; launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves, wide, wg_hot); }
     else if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
-    else if (c->parser_kind == 0) { pa.pf_ahead = pipe_lead; pa.pf_waves = pipe_pf; launch_rolz_parse_pipe(pa, nb, c->stream, c->level == 0); }
     else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
     timer_mark(c, "rolz_parse");
 }
@@ -296,7 +291,7 @@ int run_back(zlng_ctx* c, uint32_t nb, uint32_t g0, uint8_t* d_out, size_t out_c
     for (uint32_t b = g0 * G, g = g0; b < nb; b += G, g++) {
         const uint32_t n = std::min(G, nb - b);
         MtfArgs ma{c->d_tok + (size_t)b * c->tok_cap, c->d_ntok + b, n, c->tok_cap, c->d_mtf, c->d_tile_base, c->d_tile_hist,
-                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, nullptr, c->d_nfr, (c->d_dbg && c->max_blocks >= 22) ? c->d_dbg : nullptr, c->mtf_front};
+                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, nullptr, (c->d_dbg && c->max_blocks >= 22) ? c->d_dbg : nullptr};
         const bool single = G >= nb;                 // one group (always at level 0): time the serial chain by itself
         launch_lit_partition(ma, c->stream);
         if (single) timer_mark(c, "lit_partition");
@@ -374,7 +369,7 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
     if (!d_in || !d_out || ((uintptr_t)d_out & 3)) return ZLNG_E_ARG;
     const uint32_t nb = blocks_of(in_len);
     if (nb > c->max_blocks) return ZLNG_E_ARG;
-    if (!c->d_tok || !c->d_lit_byte || !c->d_snap || !c->d_nfr) return ZLNG_E_NOMEM;      // an earlier pool growth ran out of HBM
+    if (!c->d_tok || !c->d_lit_byte || !c->d_snap) return ZLNG_E_NOMEM;      // an earlier pool growth ran out of HBM
     CTX_HIP(hipSetDevice(c->device));
 
     const int entry_level = c->current_level;
@@ -492,7 +487,6 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     c->current_level = level;
     c->is_encode = is_encode != 0;
     c->max_blocks = (uint32_t)max_blocks;
-    { const char* mk = getenv("ZLNG_MTF"); c->mtf_front = mk && strcmp(mk, "front") == 0; }
     { const char* dk = getenv("ZLNG_DEC"); c->dec_plain = dk && strcmp(dk, "plain") == 0; }
     const char* pk = getenv("ZLNG_PARSER");
     c->parser_kind = !pk ? 3 : (strcmp(pk, "serial") == 0 ? 1 : (strcmp(pk, "pipe") == 0 ? 0 : (strcmp(pk, "wave") == 0 ? 2 : 3)));
@@ -551,7 +545,7 @@ void zlng_destroy(zlng_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_in, c->d_out, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_freq,
                     c->d_lens, c->d_codes, c->d_olen, c->d_sub_off, c->d_blk_end, c->d_summary, c->d_mtf, c->d_mtf_snap, c->d_dbg, c->d_subs, c->d_blocks, c->d_sub_ntok, c->d_ring, c->d_tile_base, c->d_tile_hist,
-                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, c->d_skip, c->d_nfr};
+                    c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, c->d_skip};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -602,7 +596,7 @@ int zlng_encode_parse_device(zlng_ctx* c, const void* d_in, size_t in_len) {
     if (!c || !c->is_encode || !d_in || in_len == 0) return ZLNG_E_ARG;
     const uint32_t nb = blocks_of(in_len);
     if (nb > c->max_blocks) return ZLNG_E_ARG;
-    if (!c->d_tok || !c->d_lit_byte || !c->d_snap || !c->d_nfr) return ZLNG_E_NOMEM;      // an earlier pool growth ran out of HBM
+    if (!c->d_tok || !c->d_lit_byte || !c->d_snap) return ZLNG_E_NOMEM;      // an earlier pool growth ran out of HBM
     CTX_HIP(hipSetDevice(c->device));
     const size_t nsubs = (size_t)nb * kMaxSub;
     timer_begin(c);

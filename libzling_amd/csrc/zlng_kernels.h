@@ -31,7 +31,6 @@ void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide
 // both parse blocks [a.blk0, nblocks)
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
 void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);
-void launch_rolz_parse_pipe(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);   // pf_ahead = evaluator lead (windows)
 
 // ---- K2 ------------------------------------------------------------------------------
 struct MtfArgs {
@@ -45,15 +44,13 @@ struct MtfArgs {
     uint32_t*       ctx_total; // [256]
     uint32_t*       ctx_off;   // [256] start of each context's dense run
     uint8_t*        lit_byte;  // dense literal bytes, context-major, stream order inside a context; ranks in place
-    uint8_t*        snap;      // table front (64 B) at the start of every 64-literal tile of lit_byte (same indexing)
+    uint8_t*        snap;      // the context's table (256 B, position order) at the start of every 64-literal tile of lit_byte
     uint8_t*        tile_kk;   // per tile: literals whose ranks k_mtf_replay computes from the snapshot (0 = none)
-    const uint8_t*  skip;      // optional [256]: contexts k_mtf_dense leaves alone (the measured host-chain alternative, zlng_api.hip)
-    uint8_t*        nfr;       // front / back form of the chain: rank of every literal that was outside the table front when it came (else 0)
-    unsigned long long* dbg;   // optional [512]: cycles and non-front literals per context (ZLNG_PROFILE=1 with >= 22 blocks)
-    int             front_split; // 0: k_mtf_dense + k_mtf_replay (default), 1: k_mtf_front + k_mtf_replay_front (ZLNG_MTF=front; exact, measured slower)
+    const uint8_t*  skip;      // optional [256]: contexts k_mtf_chain leaves alone (the measured host-chain alternative, zlng_api.hip)
+    unsigned long long* dbg;   // optional [512]: cycles and slow steps (literals outside the table front) per context (ZLNG_PROFILE=1 with >= 22 blocks)
 };
 void launch_lit_partition(const MtfArgs& a, hipStream_t s);   // literals -> one dense run per context
-void launch_mtf_chain(const MtfArgs& a, hipStream_t s);       // k_mtf_dense: the serial chains
+void launch_mtf_chain(const MtfArgs& a, hipStream_t s);       // k_mtf_chain: the serial chains
 void launch_mtf_finish(const MtfArgs& a, hipStream_t s);      // rank replay per tile + ranks back into the token words
 
 // ---- K3..K6 --------------------------------------------------------------------------

@@ -261,12 +261,69 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
     return (bad_level || inputter->IsErr() || outputter->IsErr()) ? -1 : 0;
 }
 
+namespace {
+
+// Decode with an ActionHandler installed: the reference pulls exactly the bytes a block consists of before it calls
+// OnProcess (src/libzling.cpp:306-336: GetChar, three GetUInt32, GetData(olen) per sub-block, the 0x00 that closes the block), and a
+// handler may itself read from the inputter inside OnProcess -- the Adler32 variant of the demo does (demo/zling.cpp:124-132) --
+// so nothing may be read ahead.  One block per GPU call; the context carries the literal tables from block to block.
+// Returns false on an I/O error (the caller still fires OnDone and returns -1, src/libzling.cpp:421-426).
+bool decode_block_by_block(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
+    CtxGuard ctx(make_ctx(0, false, 1));
+    std::vector<unsigned char> z;
+    RawBuf raw;
+    raw.resize(kBlock);
+    while (!inputter->IsEnd()) {                                          // src/libzling.cpp:306
+        z.clear();
+        bool closed = false;
+        while (!inputter->IsEnd()) {                                      // :312
+            const int flag = inputter->GetChar();
+            if (flag != 0 && flag != 1) throw std::runtime_error(zlng_strerror(ZLNG_E_FLAG));          // :315-317
+            z.push_back((unsigned char)flag);
+            if (flag == 0) { closed = true; break; }                       // :318-320
+            uint32_t hdr[3];                                               // encpos, rlen, olen (:322-324)
+            for (int k = 0; k < 3; k++) {
+                hdr[k] = inputter->GetUInt32();
+                if (inputter->IsErr()) return false;
+                for (int shift = 24; shift >= 0; shift -= 8) z.push_back((unsigned char)(hdr[k] >> shift & 0xFF));
+            }
+            if (hdr[1] > 262144u || hdr[2] > 393216u) throw std::runtime_error(zlng_strerror(ZLNG_E_BLOCKSIZE));   // :326-328
+            const size_t at = z.size(), olen = hdr[2];
+            z.resize(at + olen);
+            size_t got = 0;
+            while (!inputter->IsEnd() && got < olen) {                     // :329-332
+                got += inputter->GetData(z.data() + at + got, olen - got);
+                if (inputter->IsErr()) return false;
+            }
+            if (got < olen) throw std::runtime_error(zlng_strerror(ZLNG_E_TRUNC));   // the reference decodes what its buffer held before
+        }
+        if (z.empty()) break;
+        if (!closed) z.push_back(0);          // end of input inside a block: the reference's inner loop ends there too (:312) and writes the block
+        size_t used = 0, produced = 0, end = 0;
+        if (z.size() > 1) {
+            const int rc = zlng_decode_blocks(ctx.c, z.data(), z.size(), &used, raw.data(), raw.size(), &produced, &end);
+            if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
+            if (rc != ZLNG_OK) throw std::runtime_error(zlng_strerror(rc));
+        }
+        if (!push_all(outputter, raw.data(), produced)) return false;      // :412-415
+        handler->OnProcess(raw.data(), produced);                          // :417-419
+    }
+    return true;
+}
+
+}  // namespace
+
 int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
     if (handler) {
         handler->SetInputterOutputter(inputter, outputter, false);
         handler->OnInit();
     }
-    {
+    const char* ra = getenv("ZLNG_DECODE_READAHEAD");
+    if (handler && !(ra && atoi(ra) != 0)) {
+        // exact pull order (see decode_block_by_block); ZLNG_DECODE_READAHEAD=1 opts a handler that never touches the
+        // inputter into the batched path below
+        decode_block_by_block(inputter, outputter, handler);
+    } else {
         const int nb_full = std::min(batch_blocks(), 64);
         // Small streams are the common case for a library call: start with a 4-block context (the decode pools cost ~80 MB
         // of HBM per block) and an uninitialised buffer, and move to the full batch once the stream has filled the small one.
@@ -280,6 +337,7 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
         std::vector<size_t> ends((size_t)nb);
         const size_t chunk = 8u << 20;
         size_t zoff = 0;                                  // consumed prefix of z (compacted now and then, not per round)
+        size_t total_out = 0;                             // decoded bytes so far
         bool failed = false, eof = false, closed_tail = false;
         while (!failed) {
             if (!eof) {
@@ -315,9 +373,10 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
                 prev = ends[b];
             }
             zoff += used;
-            if (nb < nb_full && produced == (size_t)nb * kBlock) {       // a full small batch: the stream is long, take the full-size context
+            total_out += produced;
+            if (nb < nb_full && total_out >= (size_t)nb * kBlock) {      // the stream has filled the small context once over: it is long, take the full-size one
                 std::vector<unsigned char> st(ZLNG_MTF_STATE);
-                int lv = 0;
+                int lv = 0;                                               // (current_level: an encoder-side scalar, carried by the state call, unused here)
                 if (zlng_get_state(ctx.c, st.data(), &lv) != ZLNG_OK) throw std::runtime_error(zlng_strerror(ZLNG_E_DEVICE));
                 zlng_destroy(ctx.c);
                 ctx.c = nullptr;

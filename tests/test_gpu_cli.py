@@ -134,3 +134,22 @@ def test_shim_spreads_one_stream_over_devices(oracle, level, devices, batch):
     env = dict(os.environ, ZLNG_DEVICES=devices, ZLNG_BATCH_BLOCKS=str(batch))
     p = subprocess.run([DEMO, "e%d" % level], input=x.tobytes(), stdout=subprocess.PIPE, check=True, env=env)
     assert np.array_equal(np.frombuffer(p.stdout, dtype=np.uint8), want)
+
+
+def test_batched_decode_moves_to_the_full_size_context_and_keeps_the_tables(tmp_path, oracle):
+    """Decode() without handler-side reads (no handler, or ZLNG_DECODE_READAHEAD=1) starts on a 4-block context and rebuilds a
+    full-size one once the stream has produced 4 blocks, carrying the literal tables over (zlng_get_state / zlng_set_state).
+    Seven blocks of compressible data -- every one arrives inside the first 8 MiB chunk -- cross that rebuild; the literals behind
+    it only decode if the tables came along (src/libzling_lz.cpp:378-386: the decoder's Reset keeps m_mtf)."""
+    n = 6 * corpus.BLOCK + 300_000
+    unit = corpus.get("text_64k")
+    x = np.concatenate([unit] * (n // unit.size + 1))[:n].copy()
+    x[5 * corpus.BLOCK + 1000: 5 * corpus.BLOCK + 201000] = corpus.get("text_700k")[:200000]     # fresh literals behind the rebuild
+    z = oracle.encode(x, 0)
+    assert z.size < (8 << 20)
+    src = tmp_path / "in.zlng"
+    z.tofile(str(src))
+    for ra in ("1", "0"):
+        out = tmp_path / ("out%s.bin" % ra)
+        subprocess.check_call([DEMO, "d", str(src), str(out)], env=dict(os.environ, ZLNG_DECODE_READAHEAD=ra))
+        assert np.array_equal(np.fromfile(str(out), dtype=np.uint8), x)
