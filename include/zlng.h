@@ -155,19 +155,17 @@ int zlng_decode_blocks_device(zlng_ctx*, const void* d_in, size_t in_len, size_t
 int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
 
 /* Environment read when a context is created (testing / measurement aids; none of them changes the bytes produced):
- *   ZLNG_PARSER=wave|serial|pipe  cross-check forms of the block parser (default: the workgroup-wide window parser, rolz_wg.hip;
- *                                 wave = the one-wavefront parser of rounds 1-2); ZLNG_WG_WAVES=2|4|8: wavefronts per block of the default, ZLNG_WG_COMPACT=1: the paired slot records of levels 1-4 at level 0 too (default there: the wide form), ZLNG_WG_HOT=1: the hottest context's bucket mirrored in LDS
- *   ZLNG_MTF=front                the front / back form of the rank chain (exact, measured slower; default: k_mtf_dense)
- *   ZLNG_DEC=plain                the compiler-scheduled replay loop of the decoder (k_rolz_decode; default: the generated,
- *                                 software-pipelined k_rolz_replay, scripts/gen_replay_asm.py)
+ *   ZLNG_PARSER=serial            the one-lane cross-check form of the block parser (default: the workgroup-wide window parser,
+ *                                 rolz_wg.hip); ZLNG_WG_WAVES=2|4|8: wavefronts per block of the default, ZLNG_WG_COMPACT=1: the paired slot
+ *                                 records of levels 1-4 at level 0 too (default there: the wide form), ZLNG_WG_HOT=1: the hottest
+ *                                 context's bucket mirrored in LDS
  *   ZLNG_TOK_CAP=<words>          token words per block the pools start with (they grow once on overflow)
  *   ZLNG_HOST_RANK_CONTEXTS=<k>   MEASURED ALTERNATIVE, off by default: the k longest rank chains of a call are walked
  *                                 by host threads (literal runs over PCIe and back) while the device walks the others.
  *                                 The product path is all-device; this mode exists because SURVEY 8(e) asks to choose by
  *                                 measurement and bench.py reports it as a separate line.
  *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py)
- *   ZLNG_PF_AHEAD, ZLNG_PF_WAVES, ZLNG_MIN_RESTART, ZLNG_SETTLE_PF, ZLNG_LAZY_FIX   parser tuning knobs (defaults are the
- *                                 measured best); ZLNG_PIPE_LEAD, ZLNG_PIPE_PF: the same for ZLNG_PARSER=pipe
+ *   ZLNG_MIN_RESTART=-1           levels 1-4: replay every hard token by the serial code (default: the next round starts at it)
  *   ZLNG_DEBUG_PACK_LDS=<bytes>   extra dynamic LDS for the bit packer's launch (occupancy experiments)
  * (The C++ shim reads ZLNG_DEVICE, ZLNG_DEVICES, ZLNG_BATCH_BLOCKS and ZLNG_PIPELINE: INTEGRATION.md.  The build reads
  *  ZLNG_HIPCC_FLAGS and ZLNG_BUILD_FORCE (__graft_entry__.py); bench.py reads ZLNG_ENWIK9 / ZLNG_ENWIK8 (a real enwik file

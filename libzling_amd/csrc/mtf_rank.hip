@@ -14,8 +14,9 @@
 //   K2a  k_lit_tiles<hist>     per 4096-token tile: literals per context            (parallel)
 //   K2b  k_lit_scan            per context: exclusive scan over tiles in stream order (parallel)
 //   K2c  k_lit_tiles<scatter>  stable partition: literal bytes into one dense run per context
-//   K2d  k_mtf_dense           one wavefront per context walks its run: table in 4 VGPRs,
-//                              lookup = v_cmp + ballot, swap = two v_writelane  (~11 instr/literal)
+//   K2d  k_mtf_chain           one wavefront per context carries the TABLE through its run (six issue slots per
+//                              literal, table front in chain layout in one VGPR) and leaves a snapshot per 64 literals
+//   K2d' k_mtf_replay          every tile's ranks from its snapshot, one lane per tile                  (parallel)
 //   K2e  k_lit_tiles<gather>   ranks back into the token words
 #include "zlng_common.h"
 #include "zlng_kernels.h"
@@ -225,32 +226,37 @@ static_assert(chain_allow_x() == 0x3f3fff9fffffffffull, "scripts/experiments/mtf
 // Out-of-line part of step K, entered from step KN = K + 1 behind its compare (vcc is recomputed there; SCC is set again before
 // the way back, whose late branch is then evaluated a second time).  d = the literal (every active lane of PK holds it).
 //   c on a pad lane (38 / 55): it was at the head to the right (39 / 56) and the step swapped it with the pad:
-//       head = partner's symbol, partner (lane 20 = position 19 / lane 30 = position 38) = c, pad back.
-//   c nowhere in tf: leave.
+//       head = partner's symbol, partner (lane 20 = position 19 / lane 30 = position 38) = c (read back from the pad lane), pad back.
+//   c nowhere in tf (the pads and lane 0 hold values no byte equals): leave with lv = K + 1 and d = c.
 // v_readlane / v_writelane ignore EXEC; their lane selects are constants; the SGPR a v_readlane wrote is read as DATA two
 // instructions later (no wait states owed for that use); the writes of tf are four instructions ahead of step KN's DPP read.
 #define ZLNG_C_SLOW(PK, B, K, KN)                                                                               \
     "1" #K ":\n\t"                                                                                              \
-    "s_mov_b32 %[lv], " #K "+1\n\t"                                                                             \
     "v_cmp_eq_u32_sdwa vcc, %[" #PK "], %[tf] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
-    "v_readfirstlane_b32 %[d], %[" #PK "]\n\t"                                                                  \
-    "s_bfe_u32 %[d], %[d], (8 * " #B ") | (8 << 16)\n\t"                                                        \
-    "s_cbranch_vccz 9f\n\t"                                                                                     \
     "s_bitcmp1_b64 vcc, 38\n\t"                                                                                 \
     "s_cbranch_scc0 3" #K "f\n\t"                                                                               \
     "v_readlane_b32 %[da], %[tf], 20\n\t"                                                                       \
-    "v_writelane_b32 %[tf], %[d], 20\n\t"                                                                       \
+    "v_readlane_b32 %[d], %[tf], 38\n\t"                                                                        \
     "v_writelane_b32 %[tf], %[pad1], 38\n\t"                                                                    \
     "v_writelane_b32 %[tf], %[da], 39\n\t"                                                                      \
+    "v_writelane_b32 %[tf], %[d], 20\n\t"                                                                       \
     "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
     "s_branch 2" #KN "b\n\t"                                                                                    \
     "3" #K ":\n\t"                                                                                              \
+    "s_bitcmp1_b64 vcc, 55\n\t"                                                                                 \
+    "s_cbranch_scc0 4" #K "f\n\t"                                                                               \
     "v_readlane_b32 %[da], %[tf], 30\n\t"                                                                       \
-    "v_writelane_b32 %[tf], %[d], 30\n\t"                                                                       \
+    "v_readlane_b32 %[d], %[tf], 55\n\t"                                                                        \
     "v_writelane_b32 %[tf], %[pad2], 55\n\t"                                                                    \
     "v_writelane_b32 %[tf], %[da], 56\n\t"                                                                      \
+    "v_writelane_b32 %[tf], %[d], 30\n\t"                                                                       \
     "s_cmp_eq_u32 0, 0\n\t"                                                                                     \
-    "s_branch 2" #KN "b\n\t"
+    "s_branch 2" #KN "b\n\t"                                                                                    \
+    "4" #K ":\n\t"                                                                                              \
+    "v_readfirstlane_b32 %[d], %[" #PK "]\n\t"                                                                  \
+    "s_mov_b32 %[lv], " #K "+1\n\t"                                                                             \
+    "s_bfe_u32 %[d], %[d], (8 * " #B ") | (8 << 16)\n\t"                                                        \
+    "s_branch 9f\n\t"
 #define ZLNG_C_FAST(PK, Z, A, B, C, D)                                                                          \
     ZLNG_C_STEP(PK, 0, A, Z) ZLNG_C_STEP(PK, 1, B, A) ZLNG_C_STEP(PK, 2, C, B) ZLNG_C_STEP(PK, 3, D, C)
 #define ZLNG_C_COLD(PK, A, B, C, D, N)                                                                          \
@@ -325,32 +331,49 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
         for (uint32_t t = lane; t < ((n + 63u) >> 6); t += 64) tile_kk[t] = 0;
         return;
     }
-    if (n == 0) return;
+    if (n == 0) {
+        if (a.dbg && lane == 0) { a.dbg[ctx] = 0; a.dbg[256 + ctx] = 0; }
+        return;
+    }
     uint8_t* st = a.state + ctx * 256;
     const int fpos = chain_pos((int)lane);                              // (folded per lane: a 64-entry constant table)
     const uint32_t padv = 0x100u | lane;                               // what lane 0 and the pads hold: no byte equals it
-    uint32_t tf = fpos >= 0 ? (uint32_t)st[fpos] : padv;
-    uint32_t tx = lane >= ZLNG_FRONT ? (uint32_t)st[lane] : padv;      // positions 60..63 in their own lanes
+    // positions 60..63 live in the four lanes the front leaves free (0, 38, 55, 63) of a register of their own, so that ONE byte
+    // per lane -- tf's or tx's -- is the table's first 64 positions (snapshots: one select + one store)
+    const bool frontlane = fpos >= 0;
+    const uint32_t cpos = frontlane ? (uint32_t)fpos : (lane == 0 ? 60u : lane == 38 ? 61u : lane == 55 ? 62u : 63u);
+    const uint64_t padmask = (1ull << 0) | (1ull << 38) | (1ull << 55) | (1ull << 63);
+    uint32_t tf = frontlane ? (uint32_t)st[cpos] : padv;
+    uint32_t tx = frontlane ? padv : (uint32_t)st[cpos];
     uint32_t t1 = st[64 + lane], t2 = st[128 + lane], t3 = st[192 + lane];
     const uint64_t tstart = a.dbg ? __builtin_readcyclecounter() : 0;   // ZLNG_PROFILE=1 (scripts/ctx_probe.py): cycles and slow steps per context
     uint64_t n_ev = 0;
 
-    // A literal that is not in the front.  Positions 60..63 (tx) swap with front positions 57 / 57 / 58 / 59 (lanes 54 / 54 / 37 / 62);
-    // positions >= 64 stay among tx / t1..t3 (mtfnext[64] = 60): straight-line, the position from three compares, d = table[next] by
-    // three v_readlane and two selects, the two stores as v_cndmask under one-hot lane masks that are zero for the registers a
-    // position is not in (round 3's slow_step with tx in the place of t0).
+    // A literal that is not in the front.  Positions 60..63 (tx lanes 0 / 38 / 55 / 63) swap with the front positions 57 / 57 / 58 /
+    // 59 (lanes 54 / 54 / 37 / 62); positions 64..67 (t1 lanes 0..3) swap with 60..63; from 68 on a position and its partner both lie
+    // in t1..t3 (mtfnext[68] = 64): straight-line, the position from three compares, d = table[next] by two v_readlane and a select,
+    // the two stores as v_cndmask under one-hot lane masks that are zero for the registers a position is not in.
     auto slow_step = [&](uint32_t c) __attribute__((always_inline)) {
         const uint64_t mx = __builtin_amdgcn_ballot_w64(tx == c);
         if (mx) {
-            const uint32_t i = (uint32_t)__builtin_ctzll(mx);          // 60..63
-            const uint32_t fl = i <= 61u ? 54u : (i == 62u ? 37u : 62u);
+            const uint32_t l = (uint32_t)__builtin_ctzll(mx);          // 0 / 38 / 55 / 63 = position 60 / 61 / 62 / 63
+            const uint32_t fl = l <= 38u ? 54u : (l == 55u ? 37u : 62u);
             const uint32_t d = rdl(tf, fl);
-            wrl(tx, d, i);
+            wrl(tx, d, l);
             wrl(tf, c, fl);
             return;
         }
+        const uint64_t ml = __builtin_amdgcn_ballot_w64(t1 == c) & 15ull;
+        if (ml) {
+            const uint32_t k = (uint32_t)__builtin_ctzll(ml);          // position 64 + k, partner 60 + k
+            const uint32_t xl = k == 0u ? 0u : (k == 1u ? 38u : (k == 2u ? 55u : 63u));
+            const uint32_t d = rdl(tx, xl);
+            wrl(t1, d, k);
+            wrl(tx, c, xl);
+            return;
+        }
         uint64_t ma, mb, mc, oh;
-        uint32_t i, nx, a_, b_, d, d0, d1, vd;
+        uint32_t i, nx, a_, b_, d, d1, vd;
         asm volatile(
             "v_cmp_eq_u32_e64 %[ma], %[c], %[t1]\n\t"
             "v_cmp_eq_u32_e64 %[mb], %[c], %[t2]\n\t"
@@ -371,13 +394,10 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
             "s_cselect_b32 %[a], %[a], %[b]\n\t"
             "s_mul_i32 %[nx], %[i], %[a]\n\t"
             "s_lshr_b32 %[nx], %[nx], 16\n\t"
-            "v_readlane_b32 %[d0], %[t0], %[nx]\n\t"          /* lane select = nx & 63 */
-            "v_readlane_b32 %[d1], %[t1], %[nx]\n\t"
+            "v_readlane_b32 %[d1], %[t1], %[nx]\n\t"          /* lane select = nx & 63; nx is 64..140 here */
             "v_readlane_b32 %[d], %[t2], %[nx]\n\t"
             "s_cmpk_lt_u32 %[nx], 0x80\n\t"
             "s_cselect_b32 %[d], %[d1], %[d]\n\t"
-            "s_cmpk_lt_u32 %[nx], 0x40\n\t"
-            "s_cselect_b32 %[d], %[d0], %[d]\n\t"
             "v_mov_b32 %[vd], %[d]\n\t"                       /* table[i] = d */
             "s_lshl_b64 %[oh], 1, %[i]\n\t"
             "s_lshr_b32 %[a], %[i], 6\n\t"
@@ -393,17 +413,14 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
             "v_mov_b32 %[vd], %[c]\n\t"                       /* table[next] = c */
             "s_lshl_b64 %[oh], 1, %[nx]\n\t"
             "s_lshr_b32 %[a], %[nx], 6\n\t"
-            "s_cmp_eq_u32 %[a], 0\n\t"
-            "s_cselect_b64 %[ma], %[oh], 0\n\t"
             "s_cmp_eq_u32 %[a], 1\n\t"
             "s_cselect_b64 %[mb], %[oh], 0\n\t"
             "s_cmp_eq_u32 %[a], 2\n\t"
             "s_cselect_b64 %[mc], %[oh], 0\n\t"
-            "v_cndmask_b32_e64 %[t0], %[t0], %[vd], %[ma]\n\t"
             "v_cndmask_b32_e64 %[t1], %[t1], %[vd], %[mb]\n\t"
             "v_cndmask_b32_e64 %[t2], %[t2], %[vd], %[mc]\n\t"
-            : [t0] "+v"(tx), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [ma] "=&s"(ma), [mb] "=&s"(mb), [mc] "=&s"(mc), [oh] "=&s"(oh),
-              [i] "=&s"(i), [nx] "=&s"(nx), [a] "=&s"(a_), [b] "=&s"(b_), [d] "=&s"(d), [d0] "=&s"(d0), [d1] "=&s"(d1), [vd] "=&v"(vd)
+            : [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [ma] "=&s"(ma), [mb] "=&s"(mb), [mc] "=&s"(mc), [oh] "=&s"(oh),
+              [i] "=&s"(i), [nx] "=&s"(nx), [a] "=&s"(a_), [b] "=&s"(b_), [d] "=&s"(d), [d1] "=&s"(d1), [vd] "=&v"(vd)
             : [c] "s"(c)
             : "scc");
     };
@@ -429,8 +446,7 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
 #define ZLNG_C_SNAP(BASE)                                                                                          \
     {                                                                                                              \
         uint8_t* sp = snap + (size_t)(BASE) * 4;                                                                   \
-        if (fpos >= 0) sp[fpos] = (uint8_t)tf;                                                                     \
-        if (lane >= ZLNG_FRONT) sp[lane] = (uint8_t)tx;                                                            \
+        sp[cpos] = (uint8_t)sel(tf, tx, padmask);                                                                  \
         sp[64 + lane] = (uint8_t)t1; sp[128 + lane] = (uint8_t)t2; sp[192 + lane] = (uint8_t)t3;                   \
     }
     LitQuad a0, a1, a2, a3, b0, b1, b2, b3;
@@ -470,8 +486,7 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
     }
 #undef ZLNG_C_FULL_TILE
 #undef ZLNG_C_SNAP
-    if (fpos >= 0) st[fpos] = (uint8_t)tf;
-    if (lane >= ZLNG_FRONT) st[lane] = (uint8_t)tx;
+    st[cpos] = (uint8_t)sel(tf, tx, padmask);
     st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
     if (a.dbg && lane == 0) { a.dbg[ctx] = __builtin_readcyclecounter() - tstart; a.dbg[256 + ctx] = n_ev; }
 }

@@ -75,7 +75,6 @@ struct zlng_ctx {
     uint8_t*  d_lit_byte = nullptr;
     uint8_t*  d_snap = nullptr;       // rank stage: table snapshots per 64-literal tile
     uint8_t*  d_tile_kk = nullptr;
-    int       dec_plain = 0;          // ZLNG_DEC=plain selects the compiler-scheduled replay loop (k_rolz_decode) instead of the hand-written one
     // Measured ALTERNATIVE, off by default (ZLNG_HOST_RANK_CONTEXTS=k): the k longest rank chains of a
     // call are walked by host threads instead of by k_mtf_dense, overlapped with the device's other chains.  The product
     // path is all-device; bench.py reports this mode as a separate, labelled line and never as `value`.
@@ -104,9 +103,7 @@ struct zlng_ctx {
     uint32_t pending_blocks = 0;
 
     StageTimer timer;
-    int parser_kind = 3;              // 3 = workgroup-wide window parser (rolz_wg.hip; default), 2 = the one-wavefront speculative parser of
-                                      // rounds 1-2 (ZLNG_PARSER=wave), 1 = serial cross-check form (ZLNG_PARSER=serial),
-                                      // 0 = pipelined evaluator + resolver wavefronts (ZLNG_PARSER=pipe; exact, measured slower -- DESIGN.md)
+    int parser_kind = 3;              // 3 = workgroup-wide window parser (rolz_wg.hip; default), 1 = serial cross-check form (ZLNG_PARSER=serial)
 };
 
 namespace {
@@ -196,22 +193,15 @@ int alloc_token_pools(zlng_ctx* c, uint32_t tok_cap) {
 // Reset + parse of blocks [blk0, nb) under the schedule in d_sched.
 void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uint32_t blk0) {
     static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
-    static const int pf_ahead = getenv("ZLNG_PF_AHEAD") ? atoi(getenv("ZLNG_PF_AHEAD")) : 128;
-    static const int pf_env = getenv("ZLNG_PF_WAVES") ? atoi(getenv("ZLNG_PF_WAVES")) : -1;     // the wg parser: prefetch of the next window only on request (> 0): measured slower
-    static const int pf_waves = pf_env < 0 ? 1 : std::min(3, std::max(1, pf_env));
-    static const int settle_pf = getenv("ZLNG_SETTLE_PF") ? atoi(getenv("ZLNG_SETTLE_PF")) : 1;
-    static const int lazy_fix = getenv("ZLNG_LAZY_FIX") ? atoi(getenv("ZLNG_LAZY_FIX")) : 1;
-    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, pf_ahead, pf_waves,
-                 c->tok_cap, blk0, overflow_flag(c), settle_pf, lazy_fix};
+    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, c->tok_cap, blk0, overflow_flag(c)};
     static const int wg_waves = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
     static const bool wg_wide = !(getenv("ZLNG_WG_COMPACT") && atoi(getenv("ZLNG_WG_COMPACT")) != 0);   // slot plane of the wg parser at level 0 (A/B switch)
     static const bool wg_hot = getenv("ZLNG_WG_HOT") && atoi(getenv("ZLNG_WG_HOT")) != 0;     // LDS mirror of the hottest bucket (A/B switch; north_star's "LDS-staged buckets")
-    const bool wide = c->level == 0 && (c->parser_kind == 2 || (c->parser_kind == 3 && wg_wide));
+    const bool wide = c->level == 0 && c->parser_kind == 3 && wg_wide;
     launch_dict_reset(c->d_dict + (size_t)blk0 * kDictBytes, nb - blk0, c->stream, wide);
     timer_mark(c, "dict_reset");
-    if (c->parser_kind == 3) { pa.pf_waves = pf_env > 0 ? 1 : 0; launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves, wide, wg_hot); }
-    else if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
-    else launch_rolz_parse_wave(pa, nb, c->stream, c->level == 0);     // level 0: the schedule is all zeros and stays so
+    if (c->parser_kind == 1) launch_rolz_parse_serial(pa, nb, c->stream);
+    else launch_rolz_parse_wg(pa, nb, c->stream, c->level == 0, wg_waves, wide, wg_hot);
     timer_mark(c, "rolz_parse");
 }
 
@@ -487,9 +477,8 @@ zlng_ctx* zlng_create(int device, int level, int is_encode, int max_blocks, int*
     c->current_level = level;
     c->is_encode = is_encode != 0;
     c->max_blocks = (uint32_t)max_blocks;
-    { const char* dk = getenv("ZLNG_DEC"); c->dec_plain = dk && strcmp(dk, "plain") == 0; }
     const char* pk = getenv("ZLNG_PARSER");
-    c->parser_kind = !pk ? 3 : (strcmp(pk, "serial") == 0 ? 1 : (strcmp(pk, "pipe") == 0 ? 0 : (strcmp(pk, "wave") == 0 ? 2 : 3)));
+    c->parser_kind = (pk && strcmp(pk, "serial") == 0) ? 1 : 3;
     int rc = ZLNG_OK;
     auto fail = [&](int code) { *err = code; zlng_destroy(c); return (zlng_ctx*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return fail(ZLNG_E_DEVICE);
@@ -733,7 +722,7 @@ int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size
     if (nblk == 0) return sum[1] ? -(int)sum[1] : ZLNG_E_TRUNC;      // not even one complete block in the prefix
     launch_huff_decode(da, nsub, c->stream);
     timer_mark(c, "huff_decode");
-    launch_rolz_decode(da, c->dec_plain != 0, c->stream);
+    launch_rolz_decode(da, c->stream);
     timer_mark(c, "rolz_decode");
     CTX_HIP(hipMemcpyAsync(sum, c->d_summary, sizeof sum, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipMemcpyAsync(c->h_blocks.data(), c->d_blocks, nblk * sizeof(DecBlock), hipMemcpyDeviceToHost, c->stream));

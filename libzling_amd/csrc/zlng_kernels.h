@@ -15,22 +15,16 @@ struct ParseArgs {
     uint32_t*      ntok;      // NB
     const uint8_t* lvl_sched; // NB x kMaxSub: level of each sub-block (src/libzling.cpp:261-266 speculation)
     unsigned long long* dbg;  // optional NB x kDbgSlots counters (cycles per phase, rounds, redos); may be null
-    int            min_restart; // a conflict at lane >= this restarts the round there instead of replaying the token
-    int            pf_ahead;    // how many positions past its lead the far prefetch wavefront may run (tuning)
-    int            pf_waves;    // prefetch wavefronts per block (1..3)
+    int            min_restart; // levels 1-4: < 0 replays every hard token by the serial code instead of starting the next round at it (ZLNG_MIN_RESTART)
     uint32_t       tok_cap;     // token words reserved per block
     uint32_t       blk0;        // first block of this launch (a level-schedule repair re-parses a tail of the range)
     uint32_t*      overflow;    // set to 1 by a block that ran out of token words (its output is then incomplete)
-    int            settle_pf;   // wave parser: early loads for the first open lane of a window: 0 never, 1 always, 2 while
-                                // the previous round settled a lane (tuning, ZLNG_SETTLE_PF)
-    int            lazy_fix;    // wave parser, level 0: resolve lazy-only conflicts in registers (1; 0 = replay them, ZLNG_LAZY_FIX)
 };
 // the workgroup-wide parser (rolz_wg.hip): nw wavefronts per block, window of 64 nw positions
 void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0, int nw, bool wide, bool hot);   // wide: slot plane form at level 0; hot: one bucket mirrored in LDS
 void launch_dict_reset(uint8_t* dict, uint32_t nblocks, hipStream_t s, bool wide);   // wide: the slot plane form of the level-0 wave parser
-// both parse blocks [a.blk0, nblocks)
+// one lane walks the block token by token, exactly as the reference does: the on-device cross-check (ZLNG_PARSER=serial); blocks [a.blk0, nblocks)
 void launch_rolz_parse_serial(const ParseArgs& a, uint32_t nblocks, hipStream_t s);
-void launch_rolz_parse_wave(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0);
 
 // ---- K2 ------------------------------------------------------------------------------
 struct MtfArgs {
@@ -104,6 +98,6 @@ struct DecodeArgs {
 };
 void launch_frame_walk(const DecodeArgs& a, hipStream_t s);
 void launch_huff_decode(const DecodeArgs& a, uint32_t nsubs, hipStream_t s);
-void launch_rolz_decode(const DecodeArgs& a, bool plain, hipStream_t s);   // plain: the compiler-scheduled token loop (ZLNG_DEC=plain)
+void launch_rolz_decode(const DecodeArgs& a, hipStream_t s);
 
 }  // namespace zlng

@@ -19,10 +19,6 @@ zl.lib().zlng_debug_counters(C.c_void_p(s._h), buf, max(nb, 22))
 tot = s.debug_fetch(8, 0, np.uint32, 256)
 rows = sorted(((buf[c], c) for c in range(256)), reverse=True)[:8]
 for cyc, c in rows:
-    nnf = buf[256 + c] & 0xFFFFFFFF; ncp = buf[256 + c] >> 32
-    if os.environ.get("ZLNG_MTF") == "front":
-        print("ctx %3d %r: %7.1f ms  literals %9d  non-front %8d (%.1f%%) couplings %7d (%.2f%%)  %.1f ns per literal" % (
-            c, chr(c), cyc / 2.4e6, tot[c], nnf, 100.0 * nnf / max(tot[c], 1), ncp, 100.0 * ncp / max(tot[c], 1), cyc / 2.4 / max(tot[c], 1)))
-    else:
-        print("ctx %3d %r: %7.1f ms  literals %9d  tiles left by a rank >= 64: %7d (%.1f%% of the tiles)  %.1f ns per literal" % (
-            c, chr(c), cyc / 2.4e6, tot[c], nnf, 100.0 * nnf / max((tot[c] + 63) // 64, 1), cyc / 2.4 / max(tot[c], 1)))
+    nev = buf[256 + c]
+    print("ctx %3d %r: %7.1f ms  literals %9d  slow steps (literal outside the table front, rank >= 60): %7d (%.2f%% of the literals)  %.1f ns per literal" % (
+        c, chr(c), cyc / 2.4e6, tot[c], nev, 100.0 * nev / max(tot[c], 1), cyc / 2.4 / max(tot[c], 1)))

@@ -37,13 +37,16 @@ static void layout(void) {
     if (used != NFRONT || pos_of_lane[0] >= 0 || pos_of_lane[38] >= 0 || pos_of_lane[55] >= 0 || pos_of_lane[63] >= 0) { printf("layout pads\n"); exit(1); }
 }
 typedef struct { uint32_t tf[64], tx[64], t1[64], t2[64], t3[64]; } Regs;
+static int xpos(int l) { return l == 0 ? 60 : l == 38 ? 61 : l == 55 ? 62 : 63; }
+static int xlane(int p) { return p == 60 ? 0 : p == 61 ? 38 : p == 62 ? 55 : 63; }
 static uint64_t ALLOWX;
 static long n_head, n_back, n_couple;
 static void load(Regs* r, const uint8_t* tab) {
-    for (int l = 0; l < 64; l++) { r->tf[l] = pos_of_lane[l] >= 0 ? tab[pos_of_lane[l]] : 0x100u | l; r->tx[l] = l >= 60 ? tab[l] : 0x100u | l; r->t1[l] = tab[64 + l]; r->t2[l] = tab[128 + l]; r->t3[l] = tab[192 + l]; }
+    // positions 60..63 sit in the four lanes the front leaves free (0, 38, 55, 63) of a register of their own
+    for (int l = 0; l < 64; l++) { r->tf[l] = pos_of_lane[l] >= 0 ? tab[pos_of_lane[l]] : 0x100u | l; r->tx[l] = pos_of_lane[l] >= 0 ? 0x100u | l : tab[xpos(l)]; r->t1[l] = tab[64 + l]; r->t2[l] = tab[128 + l]; r->t3[l] = tab[192 + l]; }
 }
 static void store(const Regs* r, uint8_t* tab) {
-    for (int l = 0; l < 64; l++) { if (pos_of_lane[l] >= 0) tab[pos_of_lane[l]] = r->tf[l]; if (l >= 60) tab[l] = r->tx[l]; tab[64 + l] = r->t1[l]; tab[128 + l] = r->t2[l]; tab[192 + l] = r->t3[l]; }
+    for (int l = 0; l < 64; l++) { if (pos_of_lane[l] >= 0) tab[pos_of_lane[l]] = r->tf[l]; else tab[xpos(l)] = r->tx[l]; tab[64 + l] = r->t1[l]; tab[128 + l] = r->t2[l]; tab[192 + l] = r->t3[l]; }
 }
 // one literal; returns the rank
 static int step(Regs* r, uint32_t c) {
@@ -74,16 +77,17 @@ static int step(Regs* r, uint32_t c) {
     // slow step: c is at a position >= 60
     n_back++;
     int i = -1;
-    for (int l = 60; l < 64; l++) if (r->tx[l] == c) i = l;
-    for (int l = 0; l < 64; l++) { if (r->t1[l] == c) i = 64 + l; if (r->t2[l] == c) i = 128 + l; if (r->t3[l] == c) i = 192 + l; }
+    for (int l = 0; l < 64; l++) { if (r->tx[l] == c) i = xpos(l); if (r->t1[l] == c) i = 64 + l; if (r->t2[l] == c) i = 128 + l; if (r->t3[l] == c) i = 192 + l; }
     if (i < 0) { printf("lost symbol %u\n", c); exit(1); }
     const int n = nxt[i];
     uint32_t* ri = i < 64 ? r->tx : i < 128 ? r->t1 : i < 192 ? r->t2 : r->t3;
+    const int li = i < 64 ? xlane(i) : i & 63;
     uint32_t* rn; int ln;
     if (n < NFRONT) { rn = r->tf; ln = lane_of_pos[n]; n_couple++; }
-    else { rn = n < 64 ? r->tx : n < 128 ? r->t1 : n < 192 ? r->t2 : r->t3; ln = n & 63; }
+    else if (n < 64) { rn = r->tx; ln = xlane(n); }
+    else { rn = n < 128 ? r->t1 : n < 192 ? r->t2 : r->t3; ln = n & 63; }
     const uint32_t d = rn[ln];
-    ri[i & 63] = d; rn[ln] = c;
+    ri[li] = d; rn[ln] = c;
     return i;
 }
 int main(int argc, char** argv) {

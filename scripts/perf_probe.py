@@ -46,13 +46,6 @@ if os.environ.get("ZLNG_PROFILE") == "1":
     SL = 24
     buf = (C.c_ulonglong * (SL * nb))()
     zl.lib().zlng_debug_counters(C.c_void_p(s._h), buf, nb)
-    if "--all" in sys.argv and os.environ.get("ZLNG_PARSER") == "wave":
-        for b in range(nb):
-            d = buf[SL * b: SL * b + 24]
-            r = max(d[3], 1)
-            print("blk %2d: %5.0f Mcyc  rounds %6d tokens %7d  per round p1 %5.0f mask %5.0f p2 %5.0f  settled tails %.2f/round  problem tokens %.2f/round (conflicts %.2f, lazy fixes %.2f)  segments %.2f/round | p2 parts: chase+settle %4.0f validate %4.0f commit %4.0f serial %4.0f | per settled tail %4.0f cyc (%4.0f until the loads land)" % (
-                b, (d[0] + d[1] + d[2]) / 1e6, d[3], d[4], d[0] / r, d[1] / r, d[2] / r, d[17] / r, (d[6] + d[7]) / r, d[6] / r, d[20] / r, d[5] / r,
-                d[9] / r, d[15] / r, d[16] / r, d[8] / r, d[18] / max(d[17], 1), d[19] / max(d[17], 1)))
     if os.environ.get("ZLNG_PARSER", "wg") == "wg":
         for b in range(min(nb, 4) if "--all" not in sys.argv else nb):
             d = buf[SL * b: SL * b + 24]
@@ -65,21 +58,3 @@ if os.environ.get("ZLNG_PROFILE") == "1":
             print("        tables per round: rows(CAS) %5.0f closure %5.0f B1-wait %5.0f find_row %5.0f | E per iteration: rows+fix %5.0f lazy %5.0f mru %5.0f finish %5.0f closure-if-changed %5.0f Be-wait %5.0f (32-bit counters: may wrap)" % (
                 mk[0] / r, mk[1] / r, mk[2] / r, mk[3] / r, mk[4] / i, mk[5] / i, mk[6] / i, mk[7] / i, mk[8] / i, mk[9] / i))
         sys.exit(0)
-    for b in range(min(nb, 4)):
-        d = buf[SL * b: SL * b + 8]
-        e = buf[SL * b + 8: SL * b + 24]
-        if os.environ.get("ZLNG_PARSER") == "pipe":
-            print("blk %d pipe: rounds %d, wait %.0f cyc/round, resolve %.0f cyc/round, segments/round %.2f, conflicts/round %.3f (stale %.3f), word-candidates/round %.3f" % (
-                b, d[3], d[0] / max(d[3], 1), d[2] / max(d[3], 1), d[5] / max(d[3], 1), d[6] / max(d[3], 1), e[9] / max(d[3], 1), d[7] / max(d[3], 1)))
-            continue
-        print("   validate %.0f cyc/round, commit %.0f cyc/round, segments/round %.2f, problem tokens/round: conflict %.3f word-candidate %.3f" % (
-            e[7] / max(d[3], 1), e[8] / max(d[3], 1), d[5] / max(d[3], 1), d[6] / max(d[3], 1), d[7] / max(d[3], 1)))
-        print("   conflicts: same-key %d ring %d lazy-only %d | exact replays %d of which result == speculation %d" % (e[2], e[3], e[4], e[5], e[6]))
-        print("   serial-token cycles %.0fM (%.0f per problem token), chase %.0fM (%.0f per round)" % (e[0] / 1e6, e[0] / max(d[6] + d[7], 1), e[1] / 1e6, e[1] / max(d[3], 1)))
-        tot = d[0] + d[1] + d[2]
-        print("blk %d: cycles p1 %.0fM mask %.0fM p2 %.0fM | rounds %d tokens %d cand %d redo %d lazyredo %d | per round: p1 %.0f mask %.0f p2 %.0f cyc; per token p2 %.0f" % (
-            b, d[0] / 1e6, d[1] / 1e6, d[2] / 1e6, d[3], d[4], d[5], d[6], d[7], d[0] / max(d[3], 1), d[1] / max(d[3], 1), d[2] / max(d[3], 1), d[2] / max(d[4], 1)))
-if check:
-    z = dout[:m].cpu().numpy()
-    ref = Oracle().encode(x, level)
-    print("bit-exact vs oracle:", np.array_equal(z, ref))

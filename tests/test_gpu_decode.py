@@ -155,22 +155,18 @@ def test_cli_decodes_an_unterminated_final_block(tmp_path, oracle):
     assert q.returncode != 0                                           # cut inside a payload: still an error
 
 
-def test_both_replay_loops_agree(zl, oracle, monkeypatch):
-    """The generated, software-pipelined token loop (k_rolz_replay, the default) and the compiler-scheduled one (ZLNG_DEC=plain:
-    k_rolz_decode) decode the same streams to the same bytes -- text, long runs (matches longer than one wavefront, overlapping
-    copies with periods of 1..63), word-MRU tokens, incompressible bytes and a match source beyond the 64 KiB LDS window."""
+def test_replay_loop_on_runs_overlaps_and_far_sources(zl, oracle):
+    """The generated, software-pipelined token loop (k_rolz_replay; csrc/replay_loop.h) on what its special cases are for: text,
+    long runs (matches longer than one wavefront, overlapping copies with periods of 1..63), word-MRU tokens, incompressible bytes
+    and a match source beyond the 64 KiB LDS window."""
     from oracle_py import textgen
     rng = np.random.Generator(np.random.PCG64(33))
     far = textgen(300_000, 7)
     parts = [textgen(500_000, 5), np.zeros(70_000, np.uint8), np.tile(np.frombuffer(b"abcabcabd", np.uint8), 9_000),
              rng.integers(0, 256, 120_000, dtype=np.uint8), far, textgen(200_000, 6), far[:150_000],     # a copy from 350 KB back
              np.tile(np.frombuffer(b"the quick brown fox ", np.uint8), 4_000)]
+    parts += [np.tile(np.arange(p, dtype=np.uint8) + 65, 3000 // p + 40) for p in range(1, 64)]          # every copy period 1..63
     x = np.concatenate(parts)
     for lv in (0, 4):
         z = oracle.encode(x, lv)
-        monkeypatch.delenv("ZLNG_DEC", raising=False)
-        a = gpu_decode(zl, z, x.size)
-        monkeypatch.setenv("ZLNG_DEC", "plain")
-        b = gpu_decode(zl, z, x.size)
-        monkeypatch.delenv("ZLNG_DEC", raising=False)
-        assert np.array_equal(a, x) and np.array_equal(b, x), lv
+        assert np.array_equal(gpu_decode(zl, z, x.size), x), lv

@@ -313,11 +313,12 @@ def test_failed_call_leaves_the_stream_state_untouched(zl, oracle):
             s.set_state(before, 3)                                        # current_level is 0 or the context's level
 
 
-@pytest.mark.parametrize("parser", ["pipe", "serial"])
+@pytest.mark.parametrize("parser", ["serial"])
 def test_alternative_parsers_are_bit_exact(parser):
-    """The pipelined parser (rolz_pipe.hip: evaluator + resolver wavefronts, ZLNG_PARSER=pipe) and the one-lane serial form
-    are kept as cross-checks of the production parser: same bytes as the oracle at e0 and e4 on text with an incompressible
-    stretch and a sub-block cut inside a window.  (Own process: the parser is chosen when the context is created.)"""
+    """The one-lane serial form of the parser (k_rolz_parse_serial, ZLNG_PARSER=serial: the reference's loop token by token) is the
+    on-device cross-check of the production parser: same bytes as the oracle at e0 and e4 on text with an incompressible stretch
+    and a sub-block cut inside a window.  (Own process: the parser is chosen when the context is created.  The one-wavefront and
+    the pipelined parsers of rounds 1-3 are retired: scripts/experiments/retired/.)"""
     import subprocess
     import sys
     code = r'''
@@ -325,7 +326,7 @@ import sys, numpy as np
 sys.path[:0] = [%r, %r]
 import libzling_amd as zl
 from oracle_py import Oracle, textgen
-n = 2 * zl.BLOCK + 300_000 if %r == "pipe" else 700_000
+n = 700_000 if %r == "serial" else 0
 x = textgen(n, 17)
 x[n // 2: n // 2 + 300_000] = np.random.Generator(np.random.PCG64(3)).integers(0, 256, 300_000, dtype=np.uint8)
 o = Oracle()

@@ -1,15 +1,20 @@
 """Full-size checks at BASELINE.json's configuration (10^9-byte stream, 60 blocks in flight)."""
 import hashlib
+import os
+import subprocess
+import time
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_enwik9_shape_e0_matches_oracle_blockwise(oracle):
+def test_enwik9_shape_e0_matches_oracle_blockwise(oracle, manifest):
     """The whole 10^9-byte e0 stream equals the CPU oracle's, compared block by block (a checksum per block,
-    so a mismatch names the block) -- the same stream bench.py times."""
+    so a mismatch names the block) -- the same stream bench.py times -- and its SHA-256 and size are the REAL reference's
+    (tests/golden/manifest.json "config3_enwik9_shape", pinned by make_golden.py --configs from oracle/_ref)."""
     import libzling_amd as zl
     from oracle_py import textgen
     n = 1_000_000_000
@@ -18,6 +23,9 @@ def test_enwik9_shape_e0_matches_oracle_blockwise(oracle):
     with zl.Stream(0, 0, True, nb) as s:
         z = s.encode(x)
         ends = s.block_ends
+    pin = manifest["config3_enwik9_shape"]
+    assert hashlib.sha256(x.tobytes()).hexdigest() == pin["input_sha256"]
+    assert z.size == pin["zlng_bytes"] and hashlib.sha256(z.tobytes()).hexdigest() == pin["sha256"]
     ref = oracle.encode(x, 0)
     assert z.size == ref.size
     prev = 0
@@ -36,6 +44,45 @@ def test_enwik9_shape_e0_matches_oracle_blockwise(oracle):
         last = enc
         p += 13 + ol
     assert p == z.size and blocks == nb and covered == n
+
+
+def test_enwik8_shape_e0_serial_blocks_and_cli(tmp_path, manifest, capsys):
+    """BASELINE configs 1 and 2 at their own size: exactly 100,000,000 bytes (five full blocks + 16,113,920 bytes) at e0,
+    (i) through a context of ONE block, block by block ("serial 16 MB blocks": one block in flight, the literal tables carried by
+    the context), (ii) through the drop-in CLI (tools/zling_demo e0, then d) -- the harness of benchmark/benchmark.sh:22-45.
+    Both streams must be the reference's (manifest "config12_enwik8_shape", pinned from oracle/_ref)."""
+    import libzling_amd as zl
+    from libzling_amd import build
+    from oracle_py import textgen
+    build.build_all()
+    pin = manifest["config12_enwik8_shape"]
+    n = pin["bytes"]
+    x = textgen(n, 0)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == pin["input_sha256"]
+    parts = []
+    with zl.Stream(0, 0, True, 1) as s:
+        s.encode(x[: 1 << 20].copy())                 # start-up outside the clock (and a state to reset)
+        with zl.Stream(0, 0, True, 1) as fresh:
+            st0, lv0 = fresh.get_state()
+        s.set_state(st0, lv0)
+        t0 = time.perf_counter()
+        for off in range(0, n, zl.BLOCK):
+            parts.append(s.encode(x[off: off + zl.BLOCK]))
+        dt = time.perf_counter() - t0
+    z = np.concatenate(parts)
+    assert z.size == pin["zlng_bytes"] and hashlib.sha256(z.tobytes()).hexdigest() == pin["sha256"]
+    with capsys.disabled():
+        print("\n[config 2] 100,000,000 B at e0, one 16 MiB block in flight, host to host: %.2f s = %.1f MB/s" % (dt, n / dt / 1e6))
+    src, enc, dec = str(tmp_path / "enwik8.shape"), str(tmp_path / "o.zlng"), str(tmp_path / "o.bin")
+    x.tofile(src)
+    demo = os.path.join(ROOT, "tools", "zling_demo")
+    t0 = time.perf_counter(); subprocess.check_call([demo, "e0", src, enc], stderr=subprocess.DEVNULL); te = time.perf_counter() - t0
+    zc = np.fromfile(enc, dtype=np.uint8)
+    assert zc.size == pin["zlng_bytes"] and hashlib.sha256(zc.tobytes()).hexdigest() == pin["sha256"]
+    t0 = time.perf_counter(); subprocess.check_call([demo, "d", enc, dec], stderr=subprocess.DEVNULL); td = time.perf_counter() - t0
+    assert np.array_equal(np.fromfile(dec, dtype=np.uint8), x)
+    with capsys.disabled():
+        print("[config 1] zling_demo e0 %.2f s, d %.2f s (file to file, process start included), round trip PASS" % (te, td))
 
 
 def test_config4_share_e4_512_blocks_through_four_contexts(manifest):
