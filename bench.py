@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--decode", action="store_true")
     ap.add_argument("--strong", action="store_true", help="N > 1: --size is the WHOLE stream, split over the ranks (strong scaling); default: --size per GPU (weak)")
     ap.add_argument("--no-realtext", action="store_true", help="skip the second, real-text workload (value_realtext)")
+    ap.add_argument("--parses-in-flight", type=int, default=2, help="contexts of a rank's range that parse at a time (0 = all at once, the schedule of rounds 1-3)")
     ap.add_argument("--wg-waves", type=int, default=int(os.environ.get("ZLNG_WG_WAVES", "4")), help="wavefronts per block of the parser (recorded in roofline.waves_per_block)")
     args = ap.parse_args()
 
@@ -172,7 +173,7 @@ def main():
     d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
     d_in[:n].copy_(torch.from_numpy(x))
     d_in[n:].zero_()
-    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(local, args.level, True, blocks), nb, min(240, args.ctx_blocks))
+    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(local, args.level, True, blocks), nb, min(240, args.ctx_blocks), args.parses_in_flight)
     cap = zl.encode_bound(n) + 4 * len(enc.parts)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     d_state = torch.empty(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
@@ -223,6 +224,7 @@ def main():
     out_len = sum(k for _, k in segs)
     stage = enc.timings()
 
+    my_stages = enc.stage_times()                                  # [(parse, rank, huffman)] per context of this rank's range, last step
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,11 +235,19 @@ def main():
         mx = torch.tensor([stage.get("rolz_parse_max", 0.0)], dtype=torch.float64, device=cdev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         total_in, total_out, rank_sum, huff_sum, parse_max = (float(sums[0]), float(sums[1]), float(sums[2]), float(sums[3]), float(mx[0]))
+        # every rank's per-context stage times, for the schedule model (fixed-size tensor: up to 32 contexts per rank)
+        st = torch.zeros(world, 32, 3, dtype=torch.float64, device=cdev)
+        for k, v in enumerate(my_stages[:32]):
+            st[rank, k] = torch.tensor(v, dtype=torch.float64)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        all_stages = [[tuple(float(x) for x in st[r, k]) for k in range(32) if float(st[r, k].sum()) > 0.0] for r in range(world)]
     else:
         total_in, total_out = float(n), float(out_len)
         rank_sum = sum(stage.get(k, 0.0) for k in RANK_STAGES)
         huff_sum = sum(stage.get(k, 0.0) for k in ("histogram", "huff_lengths", "layout_scan", "huff_pack"))
         parse_max = stage.get("rolz_parse_max", 0.0)
+        all_stages = [my_stages]
+    model_ms = sharding.schedule_model_ranks(all_stages, enc.parses_in_flight) if (single or world == 1) else None
 
     alt_multi = None
     if world > 1 and single and not args.no_cpu_baseline:
@@ -292,7 +302,10 @@ def main():
             # what bounds the sharded stream: the parses run side by side, the rank chains one after the other
             "amdahl": {"parse_ms_max_over_ranks": round(parse_max, 3), "rank_ms_sum_over_ranks": round(rank_sum, 3),
                        "huffman_ms_sum_over_ranks": round(huff_sum, 3),
-                       "model_ms": round(parse_max + rank_sum + huff_sum, 3) if single or world == 1 else None},
+                       # the step's wall time from the stage times under the schedule that ran (sharding.schedule_model_ranks: at most
+                       # `parses_in_flight` contexts of a rank parse at a time, finishes in stream order across contexts and ranks)
+                       "parses_in_flight": enc.parses_in_flight, "contexts_per_rank": len(enc.parts),
+                       "model_ms": round(model_ms, 3) if model_ms is not None else None},
         }
         got = np.concatenate([d_out[o:o + k].cpu().numpy() for o, k in segs]) if segs else np.empty(0, np.uint8)
         if not args.no_cpu_baseline and world == 1:

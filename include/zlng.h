@@ -98,6 +98,12 @@ int zlng_encode_blocks_device(zlng_ctx*, const void* d_in, size_t in_len,
  * on the incoming MTF state, the rank + Huffman stages do.  parse -> (import state) -> finish. */
 int zlng_encode_parse_device(zlng_ctx*, const void* d_in, size_t in_len);
 int zlng_encode_finish_device(zlng_ctx*, void* d_out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+/* A range that goes through several contexts of ONE device (more than 240 blocks, or to overlap its stages): whatever is queued
+ * on `ctx` after this call starts once the parse last queued on `first` has finished.  Keeping two parses in flight makes the
+ * parses END in stream order, so that context k's rank stage (the stream-ordered part, src/libzling_lz.cpp:112-117 through the
+ * persistent tables) runs beside context k + 1's parse instead of behind all of them.  No reference counterpart: the reference
+ * has one block in flight (src/libzling.cpp:187-284). */
+int zlng_encode_parse_after(zlng_ctx* ctx, zlng_ctx* first);
 
 /* The same split with caller-owned host buffers, for a host-side pipeline over two contexts (the
  * C++ shim): zlng_encode_parse copies `in` to the device and queues the parse on

@@ -68,6 +68,7 @@ def lib():
         L.zlng_encode_blocks_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp, _szp]
         L.zlng_encode_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.zlng_encode_finish_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _szp, _szp]
+        L.zlng_encode_parse_after.argtypes = [C.c_void_p, C.c_void_p]
         L.zlng_get_state.argtypes = [C.c_void_p, _u8p, C.POINTER(C.c_int)]
         L.zlng_set_state.argtypes = [C.c_void_p, _u8p, C.c_int]
         L.zlng_get_state_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -195,6 +196,12 @@ class Stream:
         rc = lib().zlng_encode_parse_device(self._h, d_in, in_len)
         if rc != 0:
             raise ZlngError(rc, "zlng_encode_parse_device")
+
+    def parse_after(self, first):
+        """Whatever is queued on this context from now on starts after the parse last queued on `first` (same device) has finished."""
+        rc = lib().zlng_encode_parse_after(self._h, first._h)
+        if rc != 0:
+            raise ZlngError(rc, "zlng_encode_parse_after")
 
     def finish_device(self, d_out, out_cap):
         n = C.c_size_t(0)

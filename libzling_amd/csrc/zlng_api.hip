@@ -84,6 +84,7 @@ struct zlng_ctx {
     size_t    h_pinned_cap = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t  ev2 = nullptr;
+    hipEvent_t  ev_parsed = nullptr;  // recorded behind every parse queued by zlng_encode_parse[_device] (zlng_encode_parse_after waits for another context's)
     // decode pools
     DecSub*   d_subs = nullptr;
     DecBlock* d_blocks = nullptr;
@@ -371,6 +372,9 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
 #define ENC_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->last_hip_error = e_; return fail_restore(c, ZLNG_E_DEVICE); } } while (0)
 
     c->last_passes = 0;
+    // a finish that reuses a parse queued earlier: what lies between the end of that parse and this call (the contexts before it
+    // in the range being ranked) is NOT part of this context's rank stage -- it gets a stage of its own
+    if (!do_parse) timer_mark(c, "idle_before_finish");
     for (bool grown = false;; grown = true) {         // second turn only after a token-pool overflow
         if (do_parse) {
             timer_begin(c);
@@ -539,6 +543,7 @@ void zlng_destroy(zlng_ctx* c) {
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->ev_parsed) hipEventDestroy(c->ev_parsed);
     for (int i = 0; i <= kMaxStages; i++) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -594,10 +599,23 @@ int zlng_encode_parse_device(zlng_ctx* c, const void* d_in, size_t in_len) {
     CTX_HIP(hipMemcpyAsync(c->d_sched, c->h_sched.data(), nsubs, hipMemcpyHostToDevice, c->stream));
     CTX_HIP(hipMemsetAsync(overflow_flag(c), 0, 8, c->stream));
     run_front(c, static_cast<const uint8_t*>(d_in), in_len, nb, 0);
+    if (!c->ev_parsed) CTX_HIP(hipEventCreateWithFlags(&c->ev_parsed, hipEventDisableTiming));
+    CTX_HIP(hipEventRecord(c->ev_parsed, c->stream));
     c->tokens_ranked = false;
     c->pending_in = static_cast<const uint8_t*>(d_in);
     c->pending_len = in_len;
     c->pending_blocks = nb;
+    return ZLNG_OK;
+}
+
+// Everything queued on `c` from now on starts after the parse last queued on `first` has finished (same device).  A range that
+// goes through several contexts uses it to keep only two parses in flight -- parses then END in stream order and the rank stage
+// of context k runs beside the parse of context k + 1.
+int zlng_encode_parse_after(zlng_ctx* c, zlng_ctx* first) {
+    if (!c || !first || !c->is_encode || !first->is_encode || c->device != first->device) return ZLNG_E_ARG;
+    if (!first->ev_parsed) return ZLNG_OK;          // nothing was ever queued there
+    CTX_HIP(hipSetDevice(c->device));
+    CTX_HIP(hipStreamWaitEvent(c->stream, first->ev_parsed, 0));
     return ZLNG_OK;
 }
 
@@ -641,11 +659,18 @@ int zlng_set_host_rank_contexts(zlng_ctx* c, int k) {
     if (!c || !c->is_encode || k < 0) return ZLNG_E_ARG;
     k = std::min(8, k);
     CTX_HIP(hipSetDevice(c->device));
-    if (k > 0 && !c->d_skip) {
-        int rc;
-        if ((rc = dev_alloc(c, &c->d_skip, 256))) return rc;
-        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess)
-            return ZLNG_E_DEVICE;
+    if (k > 0 && !(c->d_skip && c->stream2 && c->ev2)) {        // all three or none: a half-made set is taken down again
+        int rc = ZLNG_OK;
+        if (!c->d_skip) rc = dev_alloc(c, &c->d_skip, 256);
+        if (rc == ZLNG_OK && !c->stream2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) rc = ZLNG_E_DEVICE;
+        if (rc == ZLNG_OK && !c->ev2 && hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess) rc = ZLNG_E_DEVICE;
+        if (rc != ZLNG_OK) {
+            if (c->ev2) { hipEventDestroy(c->ev2); c->ev2 = nullptr; }
+            if (c->stream2) { hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
+            if (c->d_skip) { hipFree(c->d_skip); c->d_skip = nullptr; }
+            c->host_rank_contexts = 0;
+            return rc;
+        }
     }
     c->host_rank_contexts = k;
     return ZLNG_OK;

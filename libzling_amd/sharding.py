@@ -56,10 +56,14 @@ class RangeEncoder:
                                          concatenation of its segments, not one run)
     """
 
-    def __init__(self, make_stream, nblocks, ctx_blocks=128):
+    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=2):
         self.parts = split_blocks(nblocks, ctx_blocks)
         self.streams = [make_stream(p) for p in self.parts]
         self._lens = []
+        # how many contexts parse at a time (0 = all at once, the schedule of rounds 1-3).  With two, the parse of context k + 2
+        # starts when context k's has finished: parses END in stream order, and the rank stage of context k -- which has to wait
+        # for the tables context k - 1 leaves -- runs beside the parse of context k + 1 (schedule_model below is the arithmetic)
+        self.parses_in_flight = parses_in_flight
 
     def set_host_rank_contexts(self, k):
         """The measured hybrid of SURVEY 8(e) Option C on every context of the range: the k longest rank chains of each finish are
@@ -70,8 +74,10 @@ class RangeEncoder:
     def parse(self, d_in, nbytes):
         off = 0
         self._lens = []
-        for s, p in zip(self.streams, self.parts):
+        for k, (s, p) in enumerate(zip(self.streams, self.parts)):
             n = min(p * BLOCK, nbytes - off)
+            if self.parses_in_flight > 0 and k >= self.parses_in_flight and hasattr(s, "parse_after"):
+                s.parse_after(self.streams[k - self.parses_in_flight])
             s.parse_device(d_in + off, n)
             self._lens.append(n)
             off += n
@@ -98,9 +104,45 @@ class RangeEncoder:
                     tot["rolz_parse_max"] = max(tot.get("rolz_parse_max", 0.0), v)
         return tot
 
+    def stage_times(self):
+        """[(parse_ms, rank_ms, huffman_ms)] per context of the range, in stream order (what schedule_model takes).  The rank and
+        Huffman stages are timed from the moment the context's finish was queued (`idle_before_finish` is what lay between the end
+        of its parse and that moment: the contexts before it being ranked; it is not part of any stage)."""
+        out = []
+        for s in self.streams:
+            t = dict(s.timings())
+            parse = t.get("dict_reset", 0.0) + t.get("rolz_parse", 0.0)
+            huff = sum(t.get(k, 0.0) for k in ("histogram", "huff_lengths", "layout_scan", "huff_pack"))
+            rank = sum(t.get(k, 0.0) for k in ("lit_partition", "mtf_chain", "rank_replay", "mtf_rank"))
+            out.append((parse, rank, huff))
+        return out
+
     def close(self):
         for s in self.streams:
             s.close()
+
+
+def schedule_model(stages, parses_in_flight=2):
+    """Wall time (ms) of one range from the measured stage times of its contexts, [(parse, rank, huffman)] in stream order, under
+    the schedule RangeEncoder runs: the parse of context k starts when context k - parses_in_flight's has finished (0: all start at
+    once); rank + Huffman of context k start when its parse AND the finish of context k - 1 are done (the literal tables travel in
+    stream order).  This is the Amdahl arithmetic bench.py prints as `amdahl.model_ms`: it must reproduce `ms_per_step` when the
+    stage times are right (tests/test_bench_host.py checks the arithmetic on hand-made cases)."""
+    return schedule_model_ranks([stages], parses_in_flight)
+
+
+def schedule_model_ranks(per_rank_stages, parses_in_flight=2):
+    """The same for a stream sharded over ranks: every rank parses its own contexts on its own GPU (all ranks start together),
+    and the finishes follow one another in STREAM order across the ranks -- rank r's first context waits for rank r - 1's last
+    (the 64 KiB state hand-off).  per_rank_stages[r] = [(parse, rank, huffman)] of rank r's contexts."""
+    prev = 0.0
+    for stages in per_rank_stages:
+        parse_end = []
+        for k, (parse, rank, huff) in enumerate(stages):
+            start = parse_end[k - parses_in_flight] if (parses_in_flight > 0 and k >= parses_in_flight) else 0.0
+            parse_end.append(start + parse)
+            prev = max(parse_end[k], prev) + rank + huff
+    return prev
 
 
 def run_handoff(enc, rank, world, dist, state_buf, parse, finish, load_state, store_state, initial_level):

@@ -44,3 +44,23 @@ def test_the_committed_profile_names_its_kernel_sources():
     assert len(newest["kernel_source_sha"]) == 16
     if newest["kernel_source_sha"] != bench.kernel_source_sha():
         warnings.warn("profiles/%s was taken on other kernel sources: re-run scripts/profile_round.sh" % files[-1])
+
+
+def test_schedule_model_arithmetic():
+    """sharding.schedule_model / schedule_model_ranks (what bench.py prints as amdahl.model_ms) on hand-made stage times."""
+    from libzling_amd import sharding
+    # one context: parse, then rank + Huffman
+    assert sharding.schedule_model([(500.0, 600.0, 2.0)]) == 1102.0
+    # four equal contexts, all parses at once (rounds 1-3): one parse, then four finishes in a row
+    st = [(3000.0, 1300.0, 3.0)] * 4
+    assert sharding.schedule_model(st, 0) == 3000.0 + 4 * 1303.0
+    # two parses in flight: parse ends 2000, 2000, 4000, 4000; finishes 3303, 4606, 5909, 7212
+    st = [(2000.0, 1300.0, 3.0)] * 4
+    assert sharding.schedule_model(st, 2) == 7212.0
+    # a slow third parse makes its finish wait for it: parse ends 1000, 1000, 6000, 2000(+1000 start) ...
+    st = [(1000.0, 100.0, 0.0), (1000.0, 100.0, 0.0), (5000.0, 100.0, 0.0), (1000.0, 100.0, 0.0)]
+    assert sharding.schedule_model(st, 2) == 6000.0 + 100.0 + 100.0          # ctx 3 parsed long before, waits for ctx 2's finish
+    # two ranks, one context each: both parse at once, rank 1's finish follows rank 0's
+    assert sharding.schedule_model_ranks([[(600.0, 650.0, 2.0)], [(600.0, 650.0, 2.0)]], 2) == 600.0 + 2 * 652.0
+    # ... and a rank whose parse is late holds its own finish up, not the earlier rank's
+    assert sharding.schedule_model_ranks([[(100.0, 50.0, 0.0)], [(900.0, 50.0, 0.0)]], 2) == 950.0
