@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--decode", action="store_true")
     ap.add_argument("--strong", action="store_true", help="N > 1: --size is the WHOLE stream, split over the ranks (strong scaling); default: --size per GPU (weak)")
     ap.add_argument("--no-realtext", action="store_true", help="skip the second, real-text workload (value_realtext)")
-    ap.add_argument("--parses-in-flight", type=int, default=2, help="contexts of a rank's range that parse at a time (0 = all at once, the schedule of rounds 1-3)")
+    ap.add_argument("--parses-in-flight", type=int, default=3, help="contexts of a rank's range that parse at a time (0 = all at once, the schedule of rounds 1-3)")
     ap.add_argument("--wg-waves", type=int, default=int(os.environ.get("ZLNG_WG_WAVES", "4")), help="wavefronts per block of the parser (recorded in roofline.waves_per_block)")
     args = ap.parse_args()
 

@@ -56,7 +56,7 @@ class RangeEncoder:
                                          concatenation of its segments, not one run)
     """
 
-    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=2):
+    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=3):
         self.parts = split_blocks(nblocks, ctx_blocks)
         self.streams = [make_stream(p) for p in self.parts]
         self._lens = []
