@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_layout(HuffArgs a) {
     }
     if (tid == 0) {
         a.summary[0] = carry;
-        a.summary[1] = err | (carry > a.out_cap ? 4u : 0u) | (*a.overflow ? 8u : 0u);
+        a.summary[1] = err | (carry > a.out_cap ? 4u : 0u) | (*a.overflow == 1u ? 8u : 0u) | (*a.overflow >= 2u ? 2u : 0u);   // 1: a block ran out of token words; 2: the parser reported an internal fault
     }
 }
 

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     uint32_t nt = 0;
     int q = 0, nsub = 0;
     bool overflow = false;
+    bool internal = false;                           // a "cannot happen" guard fired: reported as its own flag value (2), not as an exhausted pool
     int pf_P = -1;                                   // start of the window whose text pf_* hold (-1: none)
     uint32_t pf_wraw = 0, pf_t16 = 0;
     Quad pf_q = {0, 0, 0, 0};
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 const bool changed = (CB & lm) != 0ull;
                 if (prof) { n_iter++; c_dep += tb - ta; c_ev += td - tc; c_lim += __builtin_readcyclecounter() - td; }
                 if (!changed) break;
-                if (it > 2 * NL) { overflow = true; break; }        // cannot happen: every iteration fixes at least one token of S
+                if (it > 2 * NL) { overflow = true; internal = true; break; }   // cannot happen: every iteration fixes at least one token of S
             }
             if (prof) t3 = __builtin_readcyclecounter();
 
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 pf_t16 = ld32u(buf + (nu + 16u));
                 pf_P = q;
             } else pf_P = -1;
-            if (limit == 0 && !limit_hard) overflow = true;         // cannot happen: a round commits a token or names a hard one
+            if (limit == 0 && !limit_hard) { overflow = true; internal = true; }   // cannot happen: a round commits a token or names a hard one
             // my bits of the last iteration's buffer
             if (dep_prev) {
                 const int bl = itn & 1;
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
         nsub++;
     }
     if (tid == 0) {
-        if (overflow) { *a.overflow = 1; nsub = 0; nt = 0; }
+        if (overflow) { if (internal) atomicMax(a.overflow, 2u); else atomicMax(a.overflow, 1u); nsub = 0; nt = 0; }
         a.nsub[blk] = (uint32_t)nsub; a.ntok[blk] = nt;
     }
     if (prof && tid == 0) {

@@ -195,7 +195,11 @@ int alloc_token_pools(zlng_ctx* c, uint32_t tok_cap) {
 void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uint32_t blk0) {
     static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
     ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, c->tok_cap, blk0, overflow_flag(c)};
-    static const int wg_waves = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
+    static const int wg_waves = [] {
+        const int v = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
+        if (v != 2 && v != 4 && v != 8) fprintf(stderr, "zlng: ZLNG_WG_WAVES=%d is not 2, 4 or 8: using %d\n", v, v <= 2 ? 2 : (v <= 4 ? 4 : 8));
+        return v;
+    }();
     static const bool wg_wide = !(getenv("ZLNG_WG_COMPACT") && atoi(getenv("ZLNG_WG_COMPACT")) != 0);   // slot plane of the wg parser at level 0 (A/B switch)
     static const bool wg_hot = getenv("ZLNG_WG_HOT") && atoi(getenv("ZLNG_WG_HOT")) != 0;     // LDS mirror of the hottest bucket (A/B switch; north_star's "LDS-staged buckets")
     const bool wide = c->level == 0 && c->parser_kind == 3 && wg_wide;
@@ -404,6 +408,7 @@ int encode_device_impl(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint8_t*
             ENC_HIP(hipMemcpyAsync(c->h_cuts.data(), c->d_cuts, nsubs * sizeof(SubCut), hipMemcpyDeviceToHost, c->stream));
             ENC_HIP(hipMemcpyAsync(c->h_olen.data(), c->d_olen, nsubs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             if (hipStreamSynchronize(c->stream) != hipSuccess) return fail_restore(c, ZLNG_E_DEVICE);
+            if (of >= 2) return fail_restore(c, ZLNG_E_DEVICE);      // the parser's own fault flag: growing the pools would not help
             if (of) { overflow = true; break; }
             uint32_t bad = 0;
             if (verify_schedule(c, nb, entry_level, &final_level, &bad)) break;

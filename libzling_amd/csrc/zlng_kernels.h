@@ -18,7 +18,8 @@ struct ParseArgs {
     int            min_restart; // levels 1-4: < 0 replays every hard token by the serial code instead of starting the next round at it (ZLNG_MIN_RESTART)
     uint32_t       tok_cap;     // token words reserved per block
     uint32_t       blk0;        // first block of this launch (a level-schedule repair re-parses a tail of the range)
-    uint32_t*      overflow;    // set to 1 by a block that ran out of token words (its output is then incomplete)
+    uint32_t*      overflow;    // 1: a block ran out of token words (its output is then incomplete; the host grows the pools once and repeats);
+                                // 2: a "cannot happen" guard of the parser fired (the host fails the call, ZLNG_E_DEVICE)
 };
 // the workgroup-wide parser (rolz_wg.hip): nw wavefronts per block, window of 64 nw positions
 void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0, int nw, bool wide, bool hot);   // wide: slot plane form at level 0; hot: one bucket mirrored in LDS
