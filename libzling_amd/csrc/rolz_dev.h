@@ -364,19 +364,6 @@ __device__ __forceinline__ void speculate_from(Spec& S, uint8_t* dict, const uin
     S.lz1 = lz && want1; S.lz2 = lz && want2;
 }
 
-__device__ __forceinline__ void speculate(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t lhead2,
-                                          uint32_t risk_dist, int pos,
-                                          const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
-    uint32_t node0, ln1, ln2;
-    speculate_heads(dict, cfg, qa, ctx, hc, node0, ln1, ln2);
-    speculate_from(S, dict, buf, head0, lhead1, lhead2, risk_dist, pos, cfg, qa, ctx, hc, chk, node0, ln1, ln2);
-}
-
-// Level-0 form of speculate() (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130): the same
-// semantics written as straight-line predicated code.  Every divergent if / break in the generic form costs
-// a handful of exec-mask instructions, and one wavefront issues an instruction only every few cycles, so on
-// the level the benchmark runs the generic form spends most of phase 1 on control flow rather than on the
-// five dependent memory round trips.  Only the >16-byte tail of a long match keeps a (wave-uniform) loop.
 // Two LCP tails against the same position in one loop (level 0 compares the two newest chain nodes): both pairs
 // are at the same byte count while they are alive, so the position side is loaded once and a round in a
 // long-match region pays 8 round trips, not 16.
@@ -404,159 +391,14 @@ __device__ __forceinline__ void lcp_tail2(const uint8_t* a, const uint8_t* b, co
     r1 = r1 < (uint32_t)kMatchMax ? r1 : (uint32_t)kMatchMax;
 }
 
-// Level 0 (depth 2, one lazy probe at +1) as straight-line predicated code: five dependent round trips after the
-// window's text.  Used by the pipelined parser (rolz_pipe.hip); the wave parser runs speculate_l0w below.
-__device__ __forceinline__ void speculate_l0(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t risk_dist, int pos,
-                                             const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk) {
-    const uint32_t w4 = qa.a;
-    const uint32_t lctx1 = w4 & 0xFF;
-    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
-    Bucket B(dict, ctx), B1(dict, lctx1);
-    // round trip 1: both hash heads
-    const uint32_t node0 = B.hash[hc];
-    const uint32_t ln1 = B1.hash[hh1];
-    const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
-    // round trip 2: ring entries of the first nodes
-    const uint32_t ov0 = B.offset[node0 & (kRing - 1)];
-    const uint32_t nx = B.suffix[node0 & (kRing - 1)];
-    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)];
-    const uint32_t off0 = ov0 & 0xFFFFFF;
-    // round trip 3: compare bytes of node 0 and the ring entry of node 1
-    const bool cmp0 = has0 && (ov0 >> 24) == chk;
-    const Quad q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
-    const uint32_t nov = B.offset[nx & (kRing - 1)];
-    uint32_t len0 = cmp0 ? lcp16(qa, q0) : 0u;
-    const bool long0 = cmp0 && len0 == 16u;
-    // chain continues to node 1?  (src/libzling_lz.cpp:255-266)  Node 1 is compared before node 0's length is
-    // final: it only matters when that length is below kMatchMax, and a node-1 length can never beat kMatchMax.
-    const bool has1s = has0 && nx != 65535u;
-    const uint32_t off1 = nov & 0xFFFFFF;
-    const bool go1 = has1s && !(off0 <= off1);
-    // round trip 4: compare bytes of node 1
-    const bool cmp1 = go1 && (nov >> 24) == chk;
-    const Quad q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
-    uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
-    const bool long1 = cmp1 && len1 == 16u;
-    if (__any(long0 || long1)) {
-        uint32_t t0, t1;
-        lcp_tail2(buf + pos, buf + off0, buf + off1, long0, long1, t0, t1);
-        len0 = long0 ? t0 : len0;
-        len1 = long1 ? t1 : len1;
-    }
-    uint32_t maxlen = kMatchMin - 1, maxnode = 0;
-    if (len0 > maxlen) { maxlen = len0; maxnode = node0; }
-    const bool has1 = has1s && maxlen != (uint32_t)kMatchMax;
-    if (has1 && len1 > maxlen) { maxlen = len1; maxnode = nx; }
-    uint32_t dmin = kRing - 1;
-    dmin = has0 ? min(dmin, ring_dist(node0, head0)) : dmin;
-    dmin = has1 ? min(dmin, ring_dist(nx, head0)) : dmin;          // its offset was read for the chain-end test
-    uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
-    // round trip 5: the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1)
-    const bool lz1 = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
-    const uint32_t m = lz1 ? maxlen - 3u : 0u;
-    const uint32_t probe = ld32u(buf + ((uint32_t)pos + 1u + m));
-    const uint32_t srcw = ld32u(buf + ((lz1 && hasl) ? (lov1 & 0xFFFFFF) + m : (uint32_t)pos));
-    if (lz1 && hasl && probe == srcw) sp |= kSpVeto1;
-    const uint32_t ld1 = hasl ? ring_dist(ln1, lhead1) : (uint32_t)kRing - 1u;
-    if (ld1 < risk_dist) sp |= kSpRisk1;                                  // (kept even when no probe was needed: the conflict fix may need one)
-    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
-    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = 0; S.lctx1 = lctx1; S.lctx2 = 0;
-    S.ld1 = ld1; S.ld2 = kRing - 1;
-    S.lz1 = lz1; S.lz2 = false;
-    S.len0 = len0; S.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u); S.qa = qa;
-}
-
-constexpr uint32_t kOpenAt = 16;                     // bytes compared in phase 1 before a lane is left open (see Spec)
-
-// The wave parser's level-0 speculation: three dependent round trips after the window's text.
-//  * A ring slot carries a copy of its link's word (zlng_common.h), so node 1 needs no load of its own.  The copy was
-//    taken when node 0 was written; the reference reads the linked slot now.  They differ only if that slot has been
-//    rewritten since -- it lies in (node0, head] of the ring -- and then it holds a position later than node 0's, so
-//    the reference's chain-end test (src/libzling_lz.cpp:265, `offset[node] <= offset[next]`) stops the walk: the
-//    same outcome as having no node 1.  (The slot still counts as read: in-round conflicts are judged on it.)
-//  * Lanes whose compare reaches 16 bytes are left open (Spec); every other match is at most 15 long, so the lazy
-//    probe's two words lie within bytes 1..16 of the position (qa and `t16`, the 4 bytes after it) and bytes
-//    0..15 of the probe node's source, fetched together with the compare blocks.
-template <bool kWide>
-__device__ __forceinline__ void speculate_l0w(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t risk_dist, int pos,
-                                              const Quad qa, uint32_t t16, uint32_t ctx, uint32_t hc, uint32_t chk) {
-    const uint32_t w4 = qa.a;
-    const uint32_t lctx1 = w4 & 0xFF;
-    const uint32_t hh1 = hash_of(w4 >> 8 | qa.b << 24) % kHashSlots;
-    BucketT<kWide> B(dict, ctx), B1(dict, lctx1);
-    // round trip 1: both hash heads
-    const uint32_t node0 = B.hash[hc];
-    const uint32_t ln1 = B1.hash[hh1];
-    const bool has0 = node0 != 65535u, hasl = ln1 != 65535u;
-    // round trip 2: node 0's slot (wide: own word + its link's), its link, the probe node's word
-    uint32_t ov0, nov = 0;
-    if (kWide) { const unsigned long long sl0 = B.slot[node0 & (kRing - 1)]; ov0 = (uint32_t)sl0; nov = (uint32_t)(sl0 >> 32); }
-    else ov0 = B.offset[node0 & (kRing - 1)];
-    const uint32_t nx = B.suffix[node0 & (kRing - 1)];
-    const uint32_t lov1 = B1.offset[ln1 & (kRing - 1)];
-    const uint32_t off0 = ov0 & 0xFFFFFF;
-    const bool has1s = has0 && nx != 65535u;
-    const bool cmp0 = has0 && (ov0 >> 24) == chk;
-    Quad q0, q1, ql;
-    uint32_t off1;
-    bool cmp1;
-    if (kWide) {
-        const uint32_t dnx = (nx - node0) & (kRing - 1), age0 = (head0 - node0) & (kRing - 1);
-        const bool rewritten = dnx != 0u && dnx <= age0;
-        off1 = nov & 0xFFFFFF;
-        cmp1 = has1s && !rewritten && !(off0 <= off1) && (nov >> 24) == chk;
-        // round trip 3: compare blocks of both nodes, first 16 source bytes of the lazy probe
-        q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
-        q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
-        ql = ld128u(buf + (hasl ? (lov1 & 0xFFFFFF) : (uint32_t)pos));
-    } else {
-        // paired form (no copy of the link's word): node 1's word is a dependent load (round trip 3, beside node 0's compare block and the
-        // probe's source bytes), its compare block a fourth round trip
-        q0 = ld128u(buf + (cmp0 ? off0 : (uint32_t)pos));
-        nov = B.offset[nx & (kRing - 1)];
-        ql = ld128u(buf + (hasl ? (lov1 & 0xFFFFFF) : (uint32_t)pos));
-        off1 = nov & 0xFFFFFF;
-        cmp1 = has1s && !(off0 <= off1) && (nov >> 24) == chk;
-        q1 = ld128u(buf + (cmp1 ? off1 : (uint32_t)pos));
-    }
-    const uint32_t len0 = cmp0 ? lcp16(qa, q0) : 0u;
-    const uint32_t len1 = cmp1 ? lcp16(qa, q1) : 0u;
-    const bool long0 = cmp0 && len0 == 16u, long1 = cmp1 && len1 == 16u;
-    const bool open = long0 || long1;
-    S.off0 = off0; S.off1 = off1; S.open = open;
-    S.olen = len0 | len1 << 8 | (long0 ? 1u << 16 : 0u) | (long1 ? 1u << 17 : 0u) | (has1s ? 1u << 18 : 0u) | (nx & (kRing - 1)) << 19;
-    uint32_t maxlen = kMatchMin - 1, maxnode = 0;
-    if (len0 > maxlen) { maxlen = len0; maxnode = node0; }
-    const bool has1 = has1s && maxlen != (uint32_t)kMatchMax;
-    if (has1 && len1 > maxlen) { maxlen = len1; maxnode = nx; }
-    uint32_t dmin = kRing - 1;
-    dmin = has0 ? min(dmin, ring_dist(node0, head0)) : dmin;
-    dmin = has1 ? min(dmin, ring_dist(nx, head0)) : dmin;          // the reference reads its offset for the chain-end test
-    uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
-    // the lazy probe at pos + 1 (src/libzling_lz.cpp:291-316, depth 1): position bytes m+1 .. m+4 against source bytes
-    // m .. m+3, m = maxlen - 3 <= 12.  (An open lane's probe waits for its final length; its dmin may count node 1
-    // although node 0 turns out to have the maximum length: a conflict flagged for nothing only costs an exact replay.)
-    const bool lz1 = !open && maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
-    const uint32_t m = lz1 ? maxlen - 3u : 0u;
-    const uint32_t x0 = __builtin_amdgcn_alignbyte(qa.b, qa.a, 1u) ^ ql.a, x1 = __builtin_amdgcn_alignbyte(qa.c, qa.b, 1u) ^ ql.b;
-    const uint32_t x2 = __builtin_amdgcn_alignbyte(qa.d, qa.c, 1u) ^ ql.c, x3 = __builtin_amdgcn_alignbyte(t16, qa.d, 1u) ^ ql.d;
-    const uint32_t dw = m >> 2;
-    const uint32_t xl = dw == 0u ? x0 : dw == 1u ? x1 : dw == 2u ? x2 : x3;
-    const uint32_t xh = dw == 0u ? x1 : dw == 1u ? x2 : x3;               // (dw == 3 only with m == 12: no byte of xh is used)
-    if (lz1 && hasl && __builtin_amdgcn_alignbyte(xh, xl, m & 3u) == 0u) sp |= kSpVeto1;
-    const uint32_t ld1 = hasl ? ring_dist(ln1, lhead1) : (uint32_t)kRing - 1u;
-    if (ld1 < risk_dist) sp |= kSpRisk1;                                  // (kept even when no probe was needed: the conflict fix may need one)
-    S.sp = sp; S.node0 = node0; S.head0 = head0; S.dmin = dmin;
-    S.lkix1 = key_ix(lctx1, hh1); S.lkix2 = 0; S.lctx1 = lctx1; S.lctx2 = 0;
-    S.ld1 = ld1; S.ld2 = kRing - 1;
-    S.lz1 = lz1; S.lz2 = false;
-    S.len0 = len0; S.lsrc1 = (lov1 & 0xFFFFFF) | (hasl ? 0x80000000u : 0u); S.qa = qa;
-    S.ov0 = ov0; S.lkey1 = lctx1 << 13 | hh1;
-}
+// (The level-0 speculations of the one-wavefront and the pipelined parser -- speculate_l0, speculate_l0w with its "open lane"
+//  convention -- left with those parsers in round 4: scripts/experiments/retired/.  The workgroup-wide parser's level-0 form,
+//  speculate_l0t, lives in rolz_wg.hip; the wide slot plane it reads -- a slot's own word + a copy of the word of the slot it
+//  links to, taken when the link was made -- is described at BucketT above and in DESIGN.md, K1.)
 
 // Ordering point for LDS traffic inside ONE wavefront (program order is execution order for a wave's LDS
-// operations; this only stops the compiler from moving accesses across it).  The parser's workgroup also
-// holds a prefetch wavefront that never joins a barrier, so the main wavefront must not use s_barrier.
+// operations; this only stops the compiler from moving accesses across it).  Used where ONE wavefront of the parser's
+// workgroup works alone (the serial token of a hard lane) between two workgroup barriers.
 __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
