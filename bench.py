@@ -33,6 +33,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
+# A range that goes through several contexts (BASELINE config 4: 512 blocks per GPU = 4 contexts) gives every context its own HIP
+# stream; the runtime maps user streams onto a few hardware queues by default, and a parse that is ordered behind another
+# context's then sits in front of a rank stage of its queue (profiles/r04_b_config4_schedules.txt: 7 % of the step).  One
+# hardware queue per stream; read by the HIP runtime when it starts, so it is set before torch loads it.  A caller's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -134,7 +140,7 @@ def main():
     ap.add_argument("--decode", action="store_true")
     ap.add_argument("--strong", action="store_true", help="N > 1: --size is the WHOLE stream, split over the ranks (strong scaling); default: --size per GPU (weak)")
     ap.add_argument("--no-realtext", action="store_true", help="skip the second, real-text workload (value_realtext)")
-    ap.add_argument("--parses-in-flight", type=int, default=3, help="contexts of a rank's range that parse at a time (0 = all at once, the schedule of rounds 1-3)")
+    ap.add_argument("--parses-in-flight", type=int, default=2, help="contexts of a rank's range that parse at a time (0 = all at once, the schedule of rounds 1-3)")
     ap.add_argument("--wg-waves", type=int, default=int(os.environ.get("ZLNG_WG_WAVES", "4")), help="wavefronts per block of the parser (recorded in roofline.waves_per_block)")
     args = ap.parse_args()
 

@@ -173,6 +173,8 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py)
  *   ZLNG_MIN_RESTART=-1           levels 1-4: replay every hard token by the serial code (default: the next round starts at it)
  *   ZLNG_DEBUG_PACK_LDS=<bytes>   extra dynamic LDS for the bit packer's launch (occupancy experiments)
+ * (Not read by the library, but relevant to it: GPU_MAX_HW_QUEUES -- the HIP runtime maps user streams onto a few hardware queues by
+ *  default; a process that drives a range through several contexts at once should give every stream its own queue, as bench.py does.)
  * (The C++ shim reads ZLNG_DEVICE, ZLNG_DEVICES, ZLNG_BATCH_BLOCKS and ZLNG_PIPELINE: INTEGRATION.md.  The build reads
  *  ZLNG_HIPCC_FLAGS and ZLNG_BUILD_FORCE (__graft_entry__.py); bench.py reads ZLNG_ENWIK9 / ZLNG_ENWIK8 (a real enwik file
  *  to use instead of the generator) and ZLNG_BENCH_ONE_DEVICE (all ranks on device 0, collectives over gloo: a test hook);
