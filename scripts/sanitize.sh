@@ -8,7 +8,8 @@
 #                               "Hostcall: no handler found for service ID 4" (checked with scripts/ubench/asan_probe.hip, which writes out of
 #                               bounds on purpose); the pass is clean when that line is absent and the outputs are bit-exact.
 #   scripts/sanitize.sh host    on the GPU box: the C++ shim and zling_demo built with ASan + UBSan, the CLI tests through them
-#                               (host side of the product path: Inputter/Outputter loops, batching, the helper thread)
+#                               and the callback-protocol tests (tests/cxx/protocol_test.cpp) through them
+#                               (host side of the product path: Inputter/Outputter loops, batching, the helper thread, the exact-pull Decode)
 # Logs go to gpurun_out/ (copy what should be kept into profiles/).
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -43,6 +44,8 @@ host)
       -o $B/libzling_amd.so $ROOT/libzling_amd/cxx/*.cpp -L $ROOT/libzling_amd -lzlng_hip -Wl,-rpath,$ROOT/libzling_amd -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib || exit 1
   g++ -std=c++14 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I $ROOT/include/libzling -I $ROOT/include -o $B/zling_demo $ROOT/tools/zling_demo.cpp \
       -L $B -lzling_amd -L $ROOT/libzling_amd -lzlng_hip -Wl,-rpath,$B -Wl,-rpath,$ROOT/libzling_amd -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib || exit 1
-  ZLNG_DEMO=$B/zling_demo python -m pytest $ROOT/tests/test_gpu_cli.py -q -m gpu -p no:cacheprovider 2>&1 | tee $OUT/sanitize_host.log | tail -5
+  g++ -std=c++14 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I $ROOT/include/libzling -I $ROOT/include -o $B/protocol_test $ROOT/tests/cxx/protocol_test.cpp \
+      -L $B -lzling_amd -L $ROOT/libzling_amd -lzlng_hip -Wl,-rpath,$B -Wl,-rpath,$ROOT/libzling_amd -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -pthread || exit 1
+  ZLNG_DEMO=$B/zling_demo ZLNG_PROTOCOL_TEST=$B/protocol_test python -m pytest $ROOT/tests/test_gpu_cli.py $ROOT/tests/test_gpu_protocol.py -q -m gpu -p no:cacheprovider 2>&1 | tee $OUT/sanitize_host.log | tail -5
   ;;
 esac

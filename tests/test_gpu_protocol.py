@@ -13,7 +13,7 @@ import corpus
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "tests", "cxx", "protocol_test")
+BIN = os.environ.get("ZLNG_PROTOCOL_TEST") or os.path.join(ROOT, "tests", "cxx", "protocol_test")      # ZLNG_PROTOCOL_TEST: scripts/sanitize.sh host (the ASan build)
 
 
 def block_ends(z, trailer=0):
