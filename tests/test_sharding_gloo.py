@@ -175,3 +175,32 @@ def test_split_blocks():
         for c in (1, 7, 128, 240):
             p = sharding.split_blocks(n, c)
             assert sum(p) == n and max(p) <= c and max(p) - min(p) <= 1
+
+
+def test_range_encoder_orders_the_parses_of_its_contexts():
+    """RangeEncoder(parses_in_flight=P): the parse of context k is queued behind the parse of context k - P (zlng_encode_parse_after
+    through Stream.parse_after) and in front of nothing else; P = 0 queues every parse at once.  Recorded with streams that only log."""
+    log = []
+
+    class Rec:
+        def __init__(self, ix):
+            self.ix = ix
+
+        def parse_after(self, first):
+            log.append(("after", self.ix, first.ix))
+
+        def parse_device(self, ptr, n):
+            log.append(("parse", self.ix, n))
+
+    for pif, want in ((2, [(2, 0), (3, 1), (4, 2)]), (3, [(3, 0), (4, 1)]), (0, [])):
+        del log[:]
+        made = []
+        enc = sharding.RangeEncoder(lambda blocks: made.append(Rec(len(made))) or made[-1], 5 * 10, 10, pif)
+        assert enc.parts == [10] * 5
+        enc.parse(1 << 40, 50 * BLOCK - 123)
+        assert [(a, b) for kind, a, b in log if kind == "after"] == want
+        assert [a for kind, a, b in log if kind == "parse"] == [0, 1, 2, 3, 4]
+        for k in range(5):                                    # a context's "after" comes immediately in front of its own parse
+            if (k, k - pif) in want:
+                assert log.index(("after", k, k - pif)) + 1 == [i for i, e in enumerate(log) if e[0] == "parse" and e[1] == k][0]
+        assert sum(b for kind, a, b in log if kind == "parse") == 50 * BLOCK - 123
