@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="N > 1: --size is the WHOLE stream, split over the ranks (strong scaling); default: --size per GPU (weak)")
     ap.add_argument("--no-realtext", action="store_true", help="skip the second, real-text workload (value_realtext)")
     ap.add_argument("--parses-in-flight", type=int, default=2, help="contexts of a rank's range that parse at a time (0 = all at once, the schedule of rounds 1-3)")
+    ap.add_argument("--stagger", default="auto", help="a range through several contexts: 'auto' (one context first, one more per rank-stage duration), 'first,gap_s', or 'off' (dependency-ordered parses: --parses-in-flight)")
     ap.add_argument("--wg-waves", type=int, default=int(os.environ.get("ZLNG_WG_WAVES", "4")), help="wavefronts per block of the parser (recorded in roofline.waves_per_block)")
     args = ap.parse_args()
 
@@ -179,7 +180,9 @@ def main():
     d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
     d_in[:n].copy_(torch.from_numpy(x))
     d_in[n:].zero_()
-    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(local, args.level, True, blocks), nb, min(240, args.ctx_blocks), args.parses_in_flight)
+    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(local, args.level, True, blocks), nb, min(240, args.ctx_blocks), args.parses_in_flight,
+                                stagger=None if args.stagger == "off" else ("auto" if args.stagger == "auto" else (int(args.stagger.split(",")[0]), float(args.stagger.split(",")[1]))))
+    stag_used = [enc.stagger_plan() if enc.stagger else None]      # (first, gap_s) of the LAST step (auto: re-derived from every step's rank stages)
     cap = zl.encode_bound(n) + 4 * len(enc.parts)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     d_state = torch.empty(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
@@ -203,6 +206,8 @@ def main():
             buf.copy_(d_state.cpu())
 
     def step():
+        if enc.stagger:
+            stag_used[0] = enc.stagger_plan()
         if single:
             if rank == 0:
                 d_state.copy_(d_state0); torch.cuda.synchronize()
@@ -253,7 +258,8 @@ def main():
         huff_sum = sum(stage.get(k, 0.0) for k in ("histogram", "huff_lengths", "layout_scan", "huff_pack"))
         parse_max = stage.get("rolz_parse_max", 0.0)
         all_stages = [my_stages]
-    model_ms = sharding.schedule_model_ranks(all_stages, enc.parses_in_flight) if (single or world == 1) else None
+    stag = stag_used[0]
+    model_ms = sharding.schedule_model_ranks(all_stages, enc.parses_in_flight, (stag[0], stag[1] * 1e3) if stag else None) if (single or world == 1) else None
 
     alt_multi = None
     if world > 1 and single and not args.no_cpu_baseline:
@@ -310,7 +316,8 @@ def main():
                        "huffman_ms_sum_over_ranks": round(huff_sum, 3),
                        # the step's wall time from the stage times under the schedule that ran (sharding.schedule_model_ranks: at most
                        # `parses_in_flight` contexts of a rank parse at a time, finishes in stream order across contexts and ranks)
-                       "parses_in_flight": enc.parses_in_flight, "contexts_per_rank": len(enc.parts),
+                       "parses_in_flight": None if stag else enc.parses_in_flight, "stagger": {"first": stag[0], "gap_ms": round(stag[1] * 1e3, 1)} if stag else None,
+                       "contexts_per_rank": len(enc.parts),
                        "model_ms": round(model_ms, 3) if model_ms is not None else None},
         }
         got = np.concatenate([d_out[o:o + k].cpu().numpy() for o, k in segs]) if segs else np.empty(0, np.uint8)

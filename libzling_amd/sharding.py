@@ -56,7 +56,7 @@ class RangeEncoder:
                                          concatenation of its segments, not one run)
     """
 
-    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=3):
+    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=3, stagger=None):
         self.parts = split_blocks(nblocks, ctx_blocks)
         self.streams = [make_stream(p) for p in self.parts]
         self._lens = []
@@ -64,6 +64,15 @@ class RangeEncoder:
         # starts when context k's has finished: parses END in stream order, and the rank stage of context k -- which has to wait
         # for the tables context k - 1 leaves -- runs beside the parse of context k + 1 (schedule_model below is the arithmetic)
         self.parses_in_flight = parses_in_flight
+        # stagger = (first, gap_s) or "auto": launches spread in TIME, which no dependency between parses can express -- the first
+        # `first` contexts are queued at once, context k (k - first + 1) * gap_s seconds later by a helper thread.  With one context
+        # first and one more per rank-stage duration ("auto": gap = the rank stage's measured time per block, 10.4 ms before anything
+        # was measured, times the context's blocks) few blocks are in flight at the start, so the first parse ends early and the
+        # chain starts early; later contexts arrive at the pace the chain consumes them (profiles/r04_b: 8.08 -> 7.6 s on config 4's
+        # share).  Takes precedence over parses_in_flight.
+        self.stagger = stagger
+        self.rank_ms_per_block = 10.4
+        self._queued = []
 
     def set_host_rank_contexts(self, k):
         """The measured hybrid of SURVEY 8(e) Option C on every context of the range: the k longest rank chains of each finish are
@@ -74,23 +83,60 @@ class RangeEncoder:
     def parse(self, d_in, nbytes):
         off = 0
         self._lens = []
+        jobs = []
         for k, (s, p) in enumerate(zip(self.streams, self.parts)):
             n = min(p * BLOCK, nbytes - off)
-            if self.parses_in_flight > 0 and k >= self.parses_in_flight and hasattr(s, "parse_after"):
-                s.parse_after(self.streams[k - self.parses_in_flight])
-            s.parse_device(d_in + off, n)
+            jobs.append((k, s, d_in + off, n))
             self._lens.append(n)
             off += n
         assert off == nbytes
+        if self.stagger and len(jobs) > 1:
+            import threading
+            import time
+            first, gap = self.stagger_plan()
+            self._queued = [threading.Event() for _ in jobs]
+            t0 = time.perf_counter()
+
+            def late():
+                for k, s, ptr, n in jobs[first:]:
+                    d = t0 + (k - first + 1) * gap - time.perf_counter()
+                    if d > 0:
+                        time.sleep(d)
+                    s.parse_device(ptr, n)
+                    self._queued[k].set()
+            for k, s, ptr, n in jobs[:first]:
+                s.parse_device(ptr, n)
+                self._queued[k].set()
+            self._late = threading.Thread(target=late, daemon=True)
+            self._late.start()
+            return
+        self._queued = []
+        for k, s, ptr, n in jobs:
+            if self.parses_in_flight > 0 and k >= self.parses_in_flight and hasattr(s, "parse_after"):
+                s.parse_after(self.streams[k - self.parses_in_flight])
+            s.parse_device(ptr, n)
+
+    def stagger_plan(self):
+        """(first, gap_s) the next parse() will use."""
+        if self.stagger == "auto":
+            return 1, self.rank_ms_per_block * max(self.parts) * 1e-3
+        return int(self.stagger[0]), float(self.stagger[1])
 
     def finish(self, d_out, cap, d_state, level):
         segs, pos = [], 0
-        for s in self.streams:
+        for k, s in enumerate(self.streams):
+            if self._queued:
+                self._queued[k].wait()
             s.set_state_device(d_state, level)
             n = s.finish_device(d_out + pos, cap - pos)
             level = s.get_state_device(d_state)
             segs.append((pos, n))
             pos = (pos + n + 3) & ~3
+        if self.stagger == "auto" and hasattr(self.streams[0], "timings"):      # pace the next step by what this one measured
+            st = self.stage_times()
+            tot = sum(r for _, r, _ in st)
+            if tot > 0.0:
+                self.rank_ms_per_block = tot / sum(self.parts)
         return segs, level
 
     def timings(self):
@@ -122,24 +168,28 @@ class RangeEncoder:
             s.close()
 
 
-def schedule_model(stages, parses_in_flight=2):
+def schedule_model(stages, parses_in_flight=2, stagger=None):
     """Wall time (ms) of one range from the measured stage times of its contexts, [(parse, rank, huffman)] in stream order, under
     the schedule RangeEncoder runs: the parse of context k starts when context k - parses_in_flight's has finished (0: all start at
     once); rank + Huffman of context k start when its parse AND the finish of context k - 1 are done (the literal tables travel in
     stream order).  This is the Amdahl arithmetic bench.py prints as `amdahl.model_ms`: it must reproduce `ms_per_step` when the
     stage times are right (tests/test_bench_host.py checks the arithmetic on hand-made cases)."""
-    return schedule_model_ranks([stages], parses_in_flight)
+    return schedule_model_ranks([stages], parses_in_flight, stagger)
 
 
-def schedule_model_ranks(per_rank_stages, parses_in_flight=2):
+def schedule_model_ranks(per_rank_stages, parses_in_flight=2, stagger=None):
     """The same for a stream sharded over ranks: every rank parses its own contexts on its own GPU (all ranks start together),
     and the finishes follow one another in STREAM order across the ranks -- rank r's first context waits for rank r - 1's last
-    (the 64 KiB state hand-off).  per_rank_stages[r] = [(parse, rank, huffman)] of rank r's contexts."""
+    (the 64 KiB state hand-off).  per_rank_stages[r] = [(parse, rank, huffman)] of rank r's contexts.  stagger = (first, gap_ms):
+    context k of a rank is queued (k - first + 1) * gap_ms after the step began (k >= first) instead of behind another parse."""
     prev = 0.0
     for stages in per_rank_stages:
         parse_end = []
         for k, (parse, rank, huff) in enumerate(stages):
-            start = parse_end[k - parses_in_flight] if (parses_in_flight > 0 and k >= parses_in_flight) else 0.0
+            if stagger:
+                start = (k - stagger[0] + 1) * stagger[1] if k >= stagger[0] else 0.0
+            else:
+                start = parse_end[k - parses_in_flight] if (parses_in_flight > 0 and k >= parses_in_flight) else 0.0
             parse_end.append(start + parse)
             prev = max(parse_end[k], prev) + rank + huff
     return prev

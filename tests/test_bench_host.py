@@ -64,3 +64,17 @@ def test_schedule_model_arithmetic():
     assert sharding.schedule_model_ranks([[(600.0, 650.0, 2.0)], [(600.0, 650.0, 2.0)]], 2) == 600.0 + 2 * 652.0
     # ... and a rank whose parse is late holds its own finish up, not the earlier rank's
     assert sharding.schedule_model_ranks([[(100.0, 50.0, 0.0)], [(900.0, 50.0, 0.0)]], 2) == 950.0
+
+
+def test_schedule_model_with_time_staggered_parses():
+    """stagger = (first, gap_ms): context k is queued (k - first + 1) * gap_ms into the step."""
+    from libzling_amd import sharding
+    st = [(1900.0, 1300.0, 0.0), (2000.0, 1300.0, 0.0), (2000.0, 1300.0, 0.0), (2000.0, 1300.0, 0.0)]
+    # parses end 1900, 1200+2000 = 3200, 4400, 5600; finishes 3200, 4500, 5800, 7100
+    assert sharding.schedule_model(st, 2, (1, 1200.0)) == 7100.0
+    # a gap shorter than the chain's pace changes nothing once the chain is the bottleneck ...
+    assert sharding.schedule_model(st, 2, (1, 1000.0)) == 7100.0
+    # ... a longer one makes the last finish wait for its parse: 3 * 1500 + 2000 + 1300
+    assert sharding.schedule_model(st, 2, (1, 1500.0)) == 7800.0
+    # first = 2: two contexts at once, then one per gap
+    assert sharding.schedule_model(st, 0, (2, 1200.0)) == max(2000.0, 1900.0 + 1300.0) + 1300.0 + 1300.0 + 1300.0
