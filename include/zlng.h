@@ -171,7 +171,8 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *                                 The product path is all-device; this mode exists because SURVEY 8(e) asks to choose by
  *                                 measurement and bench.py reports it as a separate line.
  *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py)
- *   ZLNG_MIN_RESTART=-1           levels 1-4: replay every hard token by the serial code (default: the next round starts at it)
+ *   ZLNG_MIN_RESTART=-1           levels 1-4: replay every hard token by the serial code (default: the next round starts at it);
+ *                                 -2: additionally recompute the token-chain closure in full after every iteration (A/B of the incremental update)
  *   ZLNG_DEBUG_PACK_LDS=<bytes>   extra dynamic LDS for the bit packer's launch (occupancy experiments)
  * (Not read by the library, but relevant to it: GPU_MAX_HW_QUEUES -- the HIP runtime maps user streams onto a few hardware queues by
  *  default; a process that drives a range through several contexts at once should give every stream its own queue, as bench.py does.)

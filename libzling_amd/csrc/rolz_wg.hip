@@ -452,6 +452,8 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
 
             // closure of the token chain inside this wavefront: after the loop every lane knows the positions of its own
             // wavefront its chain passes (mask) and where the chain leaves the wavefront (nxg, a global lane index)
+            uint32_t cl_nxg = 0;                                    // this lane's closure, kept in registers across the iterations
+            u64 cl_mk = 0;
             auto closure = [&]() {
                 uint32_t nxg = (uint32_t)tid + tlen;
                 u64 mk = live ? lane_bit : 0ull;
@@ -464,7 +466,32 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     const u64 m2 = (u64)(uint32_t)__shfl((int)(uint32_t)(mk >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)mk, src);
                     if (go) { nxg = n2; mk |= m2; }
                 }
+                cl_nxg = nxg; cl_mk = mk;
                 c_exit[tid] = nxg; c_mask[tid] = mk;
+            };
+            // The same after the tokens of S in `changed` (a lane mask of this wavefront) took new lengths: a changed lane p only moves
+            // the chains that pass THROUGH p -- they keep what they have below p and take p's new continuation -- and the
+            // continuation of p is the closure of a lane above it, which is final once the changed lanes above p are done (highest
+            // first).  One pass of ~25 instructions per changed lane (one to three per wavefront and iteration) instead of six
+            // rounds of three ds_bpermute over all lanes; the result is the full closure's (a -DZLNG_CLOSURE_CHECK build computes both
+            // and fails the call on a difference: the encode, fuzz and real-text GPU tests pass under it).  Round 4: parse 581 -> 568 ms.
+            auto closure_update = [&](u64 changed) {
+                const uint32_t wend = (uint32_t)(64 * (wv + 1) < nlive ? 64 * (wv + 1) : nlive);
+                while (changed) {
+                    const int p = top_bit(changed);
+                    changed &= ~(1ull << p);
+                    const uint32_t t = (uint32_t)(64 * wv + p) + ufl((uint32_t)__builtin_amdgcn_readlane((int)tlen, p));
+                    u64 nm = 1ull << p;
+                    uint32_t nx = t;
+                    if (t < wend) {
+                        const int lt = (int)(t & 63u);
+                        nm |= (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cl_mk >> 32), lt) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cl_mk, lt);
+                        nx = (uint32_t)__builtin_amdgcn_readlane((int)cl_nxg, lt);
+                    }
+                    const bool through = ((cl_mk >> p) & 1ull) != 0;        // (lane p itself included)
+                    if (through) { cl_mk = (cl_mk & ((1ull << p) - 1ull)) | nm; cl_nxg = nx; }
+                }
+                c_exit[tid] = cl_nxg; c_mask[tid] = cl_mk;
             };
             closure();
             ZLNG_MK(1);
@@ -752,7 +779,19 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 ty = ty2; tlen = tlen2;
                 if (chg) a_st[tid] = ty | tlen << 8;
                 ZLNG_MK(7);
-                if (__any(chg)) closure();
+                {
+                    const u64 chm = __ballot(chg);
+                    if (chm) {
+#ifdef ZLNG_CLOSURE_CHECK
+                        closure_update(chm);
+                        const uint32_t u_n = cl_nxg; const u64 u_m = cl_mk;
+                        closure();
+                        if (live && (u_n != cl_nxg || u_m != cl_mk)) atomicMax(a.overflow, 2u);      // (no change of control flow: the flag fails the call)
+#else
+                        if (a.min_restart == -2) closure(); else closure_update(chm);      // ZLNG_MIN_RESTART=-2: the full closure, for A/B timing
+#endif
+                    }
+                }
                 ZLNG_MK(8);                          // a wavefront whose lengths did not change keeps its closure
                 if (prof) td = __builtin_readcyclecounter();
                 __syncthreads();                                    // (Be)
