@@ -199,6 +199,38 @@ def test_sharded_ranges_e4_three_ranks_with_batches(zl, oracle):
         e.close()
 
 
+@pytest.mark.parametrize("schedule", ["two_in_flight", "one_in_flight", "staggered", "auto"])
+def test_range_through_five_contexts_under_every_parse_schedule(zl, oracle, schedule):
+    """One range through five one-block contexts at e4 with the parses ordered by zlng_encode_parse_after (two / one in flight) and
+    staggered in time by RangeEncoder's helper thread: the schedule changes WHEN a parse runs, never what it produces -- the bytes
+    are the single-stream oracle encoding, twice in a row (a second step re-arms the events and the helper thread)."""
+    import torch
+    from libzling_amd import sharding
+    B = zl.BLOCK
+    total = 4 * B + 900_000
+    x = _mixed(total, 71, [(B - 300_000, 500_000), (3 * B + 100_000, 400_000)])
+    ref = oracle.encode(x, 4)
+    d_in = torch.cat([torch.from_numpy(x).cuda(), torch.zeros(512, dtype=torch.uint8, device="cuda")])
+    kw = {"two_in_flight": dict(parses_in_flight=2), "one_in_flight": dict(parses_in_flight=1),
+          "staggered": dict(stagger=(2, 0.05)), "auto": dict(stagger="auto")}[schedule]
+    enc = sharding.RangeEncoder(lambda blocks: zl.Stream(0, 4, True, blocks), 5, 1, **kw)
+    assert len(enc.streams) == 5
+    out = torch.empty(zl.encode_bound(total) + 64, dtype=torch.uint8, device="cuda")
+    st = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
+    init, lv0 = enc.streams[0].get_state()
+    for _ in range(2):
+        st[: zl.MTF_STATE].copy_(torch.from_numpy(init)); torch.cuda.synchronize()
+        enc.parse(d_in.data_ptr(), total)
+        segs, lv = enc.finish(out.data_ptr(), out.numel(), st.data_ptr(), lv0)
+        z = np.concatenate([out[a:a + k].cpu().numpy() for a, k in segs])
+        assert z.size == ref.size and np.array_equal(z, ref)
+    assert len(enc.stage_times()) == 5 and all(p > 0 and r > 0 for p, r, h in enc.stage_times())
+    with zl.Stream(0, 0, False, 1) as dec:                               # a decode context is not a parse to wait for
+        with pytest.raises(zl.ZlngError):
+            enc.streams[1].parse_after(dec)
+    enc.close()
+
+
 @pytest.mark.parametrize("level", [0, 4])
 def test_group_two_members_on_one_device(zl, oracle, level):
     """zlng_group: ONE stream over two contexts standing in for two devices (ZLNG_DEVICES=0,0 in the shim): bytes equal the
