@@ -173,6 +173,8 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *   ZLNG_PROFILE=1                parser phase counters (scripts/perf_probe.py)
  *   ZLNG_MIN_RESTART=-1           levels 1-4: replay every hard token by the serial code (default: the next round starts at it);
  *                                 -2: additionally recompute the token-chain closure in full after every iteration (A/B of the incremental update)
+ *   ZLNG_PREFIX_PCT=<0..100>      parser: after a round's first iteration, commit the tokens in front of the first changed one instead of
+ *                                 iterating when they are at least this share of the round's tokens (0 = always iterate, the default: measured within +-1 % on every workload)
  *   ZLNG_DEBUG_PACK_LDS=<bytes>   extra dynamic LDS for the bit packer's launch (occupancy experiments)
  * (Not read by the library, but relevant to it: GPU_MAX_HW_QUEUES -- the HIP runtime maps user streams onto a few hardware queues by
  *  default; a process that drives a range through several contexts at once should give every stream its own queue, as bench.py does.)

@@ -54,9 +54,12 @@ typedef struct {
 static struct {
     long rounds, tokens, iters, hard[8], serial, committed, cut_rounds, fixes, lfixes, maxit;
     long hist_it[16];
+    long prefix_rounds;
 } st;
 
 static int precise_risk = 1, only_s = 0, max_tok = 1 << 30, guess_mru = 0;
+static int prefix_pct = 0;   /* > 0: after the FIRST iteration, if the first changed token has at least prefix_pct % of the round's tokens in front of it,
+                                commit that prefix and start the next round at the changed token instead of iterating (round 4 experiment) */
 static int ring_dist(int node, int head0) { return (node - head0 - 1) & (ZO_RING - 1); }
 
 /* Read-only evaluation of `pos` as a token start against the dictionary as it is now (phase 1). */
@@ -375,13 +378,20 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                       sym += L[g].ty2 == TY_MATCH ? 2 : 1;
                   } }
                 int changed = 0;
+                static char chg_lane[MAXNL];
+                memset(chg_lane, 0, sizeof chg_lane);
                 for (int g = 0; g < limit; g++) if (S[g]) {
                     lane_t* l = &L[g];
-                    if (l->ty2 != l->ty || l->tlen2 != l->tlen) changed = 1;
+                    if (l->ty2 != l->ty || l->tlen2 != l->tlen) { changed = 1; chg_lane[g] = 1; }
                 }
                 /* (a lane whose match source / link changed but not its length: S is unchanged, later lanes saw the same S) */
                 for (int g = 0; g < nlive; g++) { lane_t* l = &L[g]; l->ty = l->ty2; l->tlen = l->tlen2; l->mlen = l->mlen2; l->mnode_slot = l->mnode2; l->link_lane = l->link2; }
                 if (!changed) break;
+                if (prefix_pct > 0 && it == 0) {
+                    int gf = -1, cf = 0, ct = 0;
+                    for (int g = 0; g < limit; g++) if (S[g]) { if (gf < 0 && chg_lane[g]) gf = g; if (gf < 0) cf++; ct++; }
+                    if (gf > 0 && cf * 100 >= prefix_pct * ct) { limit = gf; limit_is_hard = 0; st.prefix_rounds++; break; }
+                }
                 if (it > 4 * NL) { fprintf(stderr, "no convergence at P=%d\n", P); return -1; }
             }
             st.rounds++; st.iters += it + 1; st.hist_it[it < 15 ? it : 15]++; if (it + 1 > st.maxit) st.maxit = it + 1;
@@ -455,6 +465,7 @@ int main(int argc, char** argv) {
     if (argc > 7) only_s = atoi(argv[7]);
     if (argc > 8) max_tok = atoi(argv[8]);
     if (argc > 9) guess_mru = atoi(argv[9]);
+    if (argc > 10) prefix_pct = atoi(argv[10]);
     FILE* f = fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 2; }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     if (n > maxb) n = maxb;
