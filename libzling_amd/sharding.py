@@ -126,7 +126,7 @@ class RangeEncoder:
         segs, pos = [], 0
         for k, s in enumerate(self.streams):
             if self._queued:
-                self._queued[k].wait()
+                self._queued[k].wait()                     # (the helper thread of a staggered schedule has queued this context's parse)
             s.set_state_device(d_state, level)
             n = s.finish_device(d_out + pos, cap - pos)
             level = s.get_state_device(d_state)
@@ -164,6 +164,9 @@ class RangeEncoder:
         return out
 
     def close(self):
+        t = getattr(self, "_late", None)
+        if t is not None:
+            t.join()                                       # never close a context the helper thread may still queue a parse on
         for s in self.streams:
             s.close()
 
