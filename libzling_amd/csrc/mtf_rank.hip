@@ -178,9 +178,11 @@ __global__ __launch_bounds__(64) void k_ctx_offsets(MtfArgs a) {
 //   s_andn2 of the SHIFTED mask against a constant (SCC), branch one step late (behind the next compare, which only reads).
 //   Six issue slots: 14.5 ns per literal against 17.1 for round 3's seven.
 // * Out of line (entered from inside step K + 1, tf as step K left it): the literal was at a HEAD (the step has swapped it with
-//   the pad on its left: three v_writelane with constant lanes put it to its partner, 19 or 38), or it is not in the front at all:
-//   the statement is left (lv = K + 1), slow_step() walks positions 60..255 (tx / t1..t3, lane = position & 63) and the statement
-//   is re-entered at step K + 1 through a table of branches.
+//   the pad on its left: two v_readlane + three v_writelane with constant lanes put it to its partner, 19 or 38), or it is not in the
+//   front at all: the statement is left (lv = K + 1), slow_step() walks positions 60..255 (tx: positions 60..63 in the four lanes
+//   the front leaves free; t1..t3: lane = position & 63) and the statement is re-entered at step K + 1 through a table of branches.
+// scripts/experiments/mtf_chain_model.c is this step in plain C, lane by lane (tests/test_chain_model.py runs it against the
+// reference's ranks on the CPU).
 #define ZLNG_FRONT 60
 __host__ __device__ constexpr int chain_lane(int p) {                   // lane of front position p (0 <= p < ZLNG_FRONT)
     return p <= 19 ? p + 1
