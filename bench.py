@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-realtext", action="store_true", help="skip the second, real-text workload (value_realtext)")
     ap.add_argument("--parses-in-flight", type=int, default=2, help="contexts of a rank's range that parse at a time (0 = all at once, the schedule of rounds 1-3)")
     ap.add_argument("--stagger", default="auto", help="a range through several contexts: 'auto' (one context first, one more per rank-stage duration), 'first,gap_s', or 'off' (dependency-ordered parses: --parses-in-flight)")
+    ap.add_argument("--parts", default="", help="explicit block counts of the contexts of this rank's range, e.g. 64,128,128,128,64 (default: even parts of --ctx-blocks)")
     ap.add_argument("--wg-waves", type=int, default=int(os.environ.get("ZLNG_WG_WAVES", "4")), help="wavefronts per block of the parser (recorded in roofline.waves_per_block)")
     args = ap.parse_args()
 
@@ -181,7 +182,8 @@ def main():
     d_in[:n].copy_(torch.from_numpy(x))
     d_in[n:].zero_()
     enc = sharding.RangeEncoder(lambda blocks: zl.Stream(local, args.level, True, blocks), nb, min(240, args.ctx_blocks), args.parses_in_flight,
-                                stagger=None if args.stagger == "off" else ("auto" if args.stagger == "auto" else (int(args.stagger.split(",")[0]), float(args.stagger.split(",")[1]))))
+                                stagger=None if args.stagger == "off" else ("auto" if args.stagger == "auto" else (("at", [float(t) for t in args.stagger[3:].split(",")]) if args.stagger.startswith("at:") else (int(args.stagger.split(",")[0]), float(args.stagger.split(",")[1])))),
+                                parts=[int(v) for v in args.parts.split(",")] if args.parts else None)
     stag_used = [enc.stagger_plan() if enc.stagger else None]      # (first, gap_s) of the LAST step (auto: re-derived from every step's rank stages)
     cap = zl.encode_bound(n) + 4 * len(enc.parts)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -259,7 +261,7 @@ def main():
         parse_max = stage.get("rolz_parse_max", 0.0)
         all_stages = [my_stages]
     stag = stag_used[0]
-    model_ms = sharding.schedule_model_ranks(all_stages, enc.parses_in_flight, (stag[0], stag[1] * 1e3) if stag else None) if (single or world == 1) else None
+    model_ms = sharding.schedule_model_ranks(all_stages, enc.parses_in_flight, (("at", [t * 1e3 for t in stag[1]]) if stag and stag[0] == "at" else ((stag[0], stag[1] * 1e3) if stag else None))) if (single or world == 1) else None
 
     alt_multi = None
     if world > 1 and single and not args.no_cpu_baseline:
@@ -316,7 +318,7 @@ def main():
                        "huffman_ms_sum_over_ranks": round(huff_sum, 3),
                        # the step's wall time from the stage times under the schedule that ran (sharding.schedule_model_ranks: at most
                        # `parses_in_flight` contexts of a rank parse at a time, finishes in stream order across contexts and ranks)
-                       "parses_in_flight": None if stag else enc.parses_in_flight, "stagger": {"first": stag[0], "gap_ms": round(stag[1] * 1e3, 1)} if stag else None,
+                       "parses_in_flight": None if stag else enc.parses_in_flight, "stagger": ({"at_ms": [round(t * 1e3) for t in stag[1]]} if stag and stag[0] == "at" else ({"first": stag[0], "gap_ms": round(stag[1] * 1e3, 1)} if stag else None)),
                        "contexts_per_rank": len(enc.parts),
                        "model_ms": round(model_ms, 3) if model_ms is not None else None},
         }

@@ -56,8 +56,9 @@ class RangeEncoder:
                                          concatenation of its segments, not one run)
     """
 
-    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=3, stagger=None):
-        self.parts = split_blocks(nblocks, ctx_blocks)
+    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=3, stagger=None, parts=None):
+        self.parts = list(parts) if parts else split_blocks(nblocks, ctx_blocks)     # parts: explicit block counts of the contexts
+        assert sum(self.parts) == nblocks and all(0 < p <= 240 for p in self.parts)
         self.streams = [make_stream(p) for p in self.parts]
         self._lens = []
         # how many contexts parse at a time (0 = all at once, the schedule of rounds 1-3).  With two, the parse of context k + 2
@@ -93,13 +94,19 @@ class RangeEncoder:
         if self.stagger and len(jobs) > 1:
             import threading
             import time
-            first, gap = self.stagger_plan()
+            plan = self.stagger_plan()
+            if plan[0] == "at":                          # explicit launch times (seconds into the step), one per context
+                at = list(plan[1])
+                first = sum(1 for t in at if t <= 0.0)
+            else:
+                first, gap = plan
+                at = [0.0 if k < first else (k - first + 1) * gap for k in range(len(jobs))]
             self._queued = [threading.Event() for _ in jobs]
             t0 = time.perf_counter()
 
             def late():
                 for k, s, ptr, n in jobs[first:]:
-                    d = t0 + (k - first + 1) * gap - time.perf_counter()
+                    d = t0 + at[k] - time.perf_counter()
                     if d > 0:
                         time.sleep(d)
                     s.parse_device(ptr, n)
@@ -120,6 +127,8 @@ class RangeEncoder:
         """(first, gap_s) the next parse() will use."""
         if self.stagger == "auto":
             return 1, self.rank_ms_per_block * max(self.parts) * 1e-3
+        if self.stagger[0] == "at":
+            return "at", [float(t) for t in self.stagger[1]]
         return int(self.stagger[0]), float(self.stagger[1])
 
     def finish(self, d_out, cap, d_state, level):
@@ -189,7 +198,9 @@ def schedule_model_ranks(per_rank_stages, parses_in_flight=2, stagger=None):
     for stages in per_rank_stages:
         parse_end = []
         for k, (parse, rank, huff) in enumerate(stages):
-            if stagger:
+            if stagger and stagger[0] == "at":
+                start = stagger[1][k]
+            elif stagger:
                 start = (k - stagger[0] + 1) * stagger[1] if k >= stagger[0] else 0.0
             else:
                 start = parse_end[k - parses_in_flight] if (parses_in_flight > 0 and k >= parses_in_flight) else 0.0

@@ -78,3 +78,10 @@ def test_schedule_model_with_time_staggered_parses():
     assert sharding.schedule_model(st, 2, (1, 1500.0)) == 7800.0
     # first = 2: two contexts at once, then one per gap
     assert sharding.schedule_model(st, 0, (2, 1200.0)) == max(2000.0, 1900.0 + 1300.0) + 1300.0 + 1300.0 + 1300.0
+
+
+def test_schedule_model_with_explicit_launch_times():
+    from libzling_amd import sharding
+    st = [(1500.0, 600.0, 0.0), (2000.0, 1300.0, 0.0), (2000.0, 1300.0, 0.0)]
+    # parses end 1500, 300 + 2000, 1300 + 2000; finishes 2100, 3600, 4900
+    assert sharding.schedule_model(st, 2, ("at", [0.0, 300.0, 1300.0])) == 4900.0
