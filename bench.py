@@ -102,6 +102,92 @@ def traffic_of(kernel, size, level, source, world):
     return None, None
 
 
+def zlng_block_ends(z):
+    """Offset behind every block of a .zlng stream (sub-blocks `01 encpos rlen olen payload`, then `00`)."""
+    ends, p, n = [], 0, len(z)
+    while p < n:
+        if z[p] == 0:
+            p += 1
+            ends.append(p)
+        else:
+            p += 13 + int.from_bytes(z[p + 9: p + 13].tobytes(), "big")
+    return ends
+
+
+def expected_ranges(args, world, single, source, ranges, live_max_bytes):
+    """What every rank's bytes must be, [(zlng_bytes, sha256)] in rank order, and where that comes from -- the reference's
+    benchmark never prints a time without `cmp` (benchmark/benchmark.sh:29-39), so no line of this one goes without it either:
+      "pins"            tests/golden/manifest.json `sharded_ranges`: the REAL reference run over the whole N x 10^9-byte (weak) or
+                        10^9-byte (--strong) stream in the build container (tests/golden/make_golden.py --ranges), per sharding.plan range;
+      "reference-live"  any other size up to --parity-live-max-mib: the CPU encoder (the real reference when oracle/_ref is there)
+                        over the whole stream on rank 0's host, now, sliced at its block ends.
+    (None, why) when neither applies (a stream too large to re-encode on the host inside a bench run, or --no-cpu-baseline)."""
+    if not single and world > 1:
+        return None, "--shard streams: N unrelated streams, no single reference stream to compare with"
+    total = sum(n for _, n in ranges)
+    try:
+        pins = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json"))).get("sharded_ranges")
+    except Exception:
+        pins = None
+    if pins and source == "synthetic" and args.level == pins["level"]:
+        key = None
+        if world > 1 and args.strong and args.size == pins["per_gpu_bytes"]:
+            key = pins["strong"].get(str(world))
+        elif not (world > 1 and args.strong) and args.size == pins["per_gpu_bytes"]:
+            key = pins["weak"].get(str(world))
+        if key and [(r["offset"], r["bytes"]) for r in key["ranks"]] == [tuple(r) for r in ranges]:
+            return [(r["zlng_bytes"], r["sha256"]) for r in key["ranks"]], "pins (tests/golden/manifest.json sharded_ranges: the real reference over the whole %d-byte stream)" % total
+    if args.no_cpu_baseline:
+        return None, "--no-cpu-baseline"
+    if total > live_max_bytes:
+        return None, "no pin for this stream and %d B is above --parity-live-max-mib" % total
+    x, _ = load_input(total, 0)
+    cpu, kind = cpu_encoder()
+    z = cpu.encode(x, args.level)
+    ends = [0] + zlng_block_ends(z)
+    out = []
+    for off, n in ranges:
+        seg = z[ends[off // BLOCK]: ends[(off + n + BLOCK - 1) // BLOCK]]
+        out.append((int(seg.size), hashlib.sha256(seg.tobytes()).hexdigest()))
+    return out, "%s-live (the CPU encoder over the whole %d-byte stream on rank 0's host in this run)" % (kind, total)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_multistream(level, mib=128):
+    """SURVEY 8(d)'s context line: the reference is single-threaded and ONE stream cannot use more than one core, but a host
+    has many -- K independent streams of `mib` MiB (textgen chunks far apart) on K threads, aggregate MB/s.  K = min(cores, 16)."""
+    import threading
+    from oracle_py import textgen
+    cores = os.cpu_count() or 1
+    k = max(1, min(cores, 16))
+    cpu, kind = cpu_encoder()
+    xs = [textgen(mib << 20, 100_000 + 64 * i) for i in range(k)]
+    encs = [cpu] + [cpu_encoder()[0] for _ in range(k - 1)]
+    outs = [0] * k
+
+    def run(i):
+        outs[i] = int(encs[i].encode(xs[i], level).size)          # ctypes releases the GIL for the call
+    th = [threading.Thread(target=run, args=(i,)) for i in range(k)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": round(k * (mib << 20) / dt / 1e6, 2), "unit": "MB/s", "cores": k, "host_cores_online": cores, "cpu": cpu_model(), "kind": kind,
+            "sample": "%d independent streams of %d MiB (synthetic text) on %d threads, e%d; a context line: one .zlng stream is one serial "
+                      "encode in the reference, so this is a number about %d files, not about the metric's one stream" % (k, mib, k, level, k)}
+
+
 def rank_chain_line(x, level, hot_literals_gpu, mtf_ms):
     """ns per literal of the hottest context's serial rank chain (src/libzling_lz.cpp:112-117): on the GPU (stage time / that
     context's literals -- the stage is bounded by its longest chain) and on one host core (the reference's own
@@ -136,6 +222,8 @@ def main():
     ap.add_argument("--shard", choices=["single-stream", "streams"], default="single-stream")
     ap.add_argument("--ctx-blocks", type=int, default=128, help="blocks per context (a rank uses as many contexts as its range needs)")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    ap.add_argument("--parity-live-max-mib", type=int, default=3072, help="a stream without pinned per-rank SHA-256 values is re-encoded whole by the CPU encoder on rank 0 for the parity column, up to this size")
+    ap.add_argument("--no-multistream", action="store_true", help="skip cpu_baseline_multistream (K streams on K host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode", action="store_true")
     ap.add_argument("--strong", action="store_true", help="N > 1: --size is the WHOLE stream, split over the ranks (strong scaling); default: --size per GPU (weak)")
@@ -171,11 +259,13 @@ def main():
     # ---- this rank's share of the workload
     single = args.shard == "single-stream" and world > 1
     if single:
-        off, n = (sharding.plan(args.size, world) if args.strong else sharding.plan(args.size * world, world, per_rank_bytes=args.size))[rank]
+        ranges = sharding.plan(args.size, world) if args.strong else sharding.plan(args.size * world, world, per_rank_bytes=args.size)
+        off, n = ranges[rank]
         first_chunk = off // BLOCK
     else:
         n = args.size
         first_chunk = rank * 4096                                   # distinct stream per rank
+        ranges = [(0, n)]
     x, source = load_input(n, first_chunk)
     nb = (n + BLOCK - 1) // BLOCK
     d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
@@ -263,6 +353,24 @@ def main():
     stag = stag_used[0]
     model_ms = sharding.schedule_model_ranks(all_stages, enc.parses_in_flight, (("at", [t * 1e3 for t in stag[1]]) if stag and stag[0] == "at" else ((stag[0], stag[1] * 1e3) if stag else None))) if (single or world == 1) else None
 
+    # ---- what every rank produced: size and SHA-256 of its own bytes, gathered on all ranks (40 bytes each)
+    def seg_bytes(sg):
+        return np.concatenate([d_out[o:o + k].cpu().numpy() for o, k in sg]) if sg else np.empty(0, np.uint8)
+
+    def gather_digests(buf):
+        mine = np.frombuffer(int(buf.size).to_bytes(8, "little") + hashlib.sha256(buf.tobytes()).digest(), dtype=np.uint8)
+        if world == 1:
+            rows = [mine]
+        else:
+            t = torch.from_numpy(mine.copy()).to(cdev)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            rows = [q.cpu().numpy() for q in parts]
+        return [(int.from_bytes(r[:8].tobytes(), "little"), r[8:].tobytes().hex()) for r in rows]
+
+    got = seg_bytes(segs)
+    per_rank = gather_digests(got)
+
     alt_multi = None
     if world > 1 and single and not args.no_cpu_baseline:
         # SURVEY 8(e) "choose by measurement": the same sharded stream with the k longest rank chains of every range on host
@@ -276,13 +384,16 @@ def main():
         dta = (time.perf_counter() - t1) / max(1, args.steps - 1)
         st_alt = enc.timings()
         enc.set_host_rank_contexts(0)
+        per_rank_alt = gather_digests(seg_bytes(segs_alt))
         ta = torch.tensor([dta, sum(st_alt.get(k, 0.0) for k in RANK_STAGES), st_alt.get("rolz_parse_max", 0.0)], dtype=torch.float64, device=cdev)
         tmax = ta.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = ta.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         alt_multi = {"value": round(total_in / float(tmax[0]) / 1e6, 2), "unit": "MB/s", "ms_per_step": round(float(tmax[0]) * 1e3, 3), "host_threads_per_rank": 4,
+                     "identical_bytes": bool(per_rank_alt == per_rank),
                      "amdahl": {"parse_ms_max_over_ranks": round(float(tmax[2]), 3), "rank_ms_sum_over_ranks": round(float(tsum[1]), 3)},
                      "note": "NOT the product path and not `value`: the 4 longest rank chains of every rank's range on host threads (SURVEY 8(e) Option C); "
-                             "the all-device chain does not shard (one serial chain per context over the whole stream), this is the measured way out"}
+                             "the all-device chain does not shard (one serial chain per context over the whole stream), this is the measured way out; "
+                             "identical_bytes: every rank's size + SHA-256 equal to the all-device run's"}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_in * args.steps / dt / 1e6
@@ -308,6 +419,7 @@ def main():
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes": int(alg_bytes), "kernel_source_sha": kernel_source_sha(),
+                         "scope": "rank 0's launch of the dominant kernel over rank 0's range (every rank launches the same kernels on its own range)" if world > 1 else "the one launch over the whole stream",
                          # occupancy of the chip by the two serial kernels: the parser runs one workgroup per 16 MiB block, the rank
                          # chain one wavefront per context (256); 256 CUs x 4 SIMDs on the chip
                          "blocks_in_flight": int(nb), "waves_per_block": int(args.wg_waves),
@@ -322,10 +434,16 @@ def main():
                        "contexts_per_rank": len(enc.parts),
                        "model_ms": round(model_ms, 3) if model_ms is not None else None},
         }
-        got = np.concatenate([d_out[o:o + k].cpu().numpy() for o, k in segs]) if segs else np.empty(0, np.uint8)
-        if not args.no_cpu_baseline and world == 1:
+        # ---- the PASS/FAIL column (benchmark/benchmark.sh:29-39 never reports a time without `cmp`): every rank's bytes against
+        # the reference's bytes for that rank's range
+        want, wsrc = expected_ranges(args, world, single, source, ranges, args.parity_live_max_mib << 20)
+        res["zlng_per_rank"] = [{"rank": r, "zlng_bytes": k, "sha256": h} for r, (k, h) in enumerate(per_rank)]
+        ranges_ok = None if want is None else bool([tuple(w) for w in want] == [tuple(g) for g in per_rank])
+        res["parity_ranges"] = {"ok": ranges_ok, "source": wsrc}
+        prefix_ok = None
+        if not args.no_cpu_baseline:
             # host-to-host entry point (pageable H2D of the input + D2H of the .zlng inside the call), SURVEY 8(d)
-            if nb <= 240:
+            if nb <= 240 and world == 1:
                 with zl.Stream(local, args.level, True, nb) as hs:
                     out_h = np.zeros(zl.encode_bound(n), np.uint8)          # pages touched before the timed calls
                     hs.encode_into(x, out_h)
@@ -341,24 +459,30 @@ def main():
                                         "`value` with the input already resident in HBM when the clock starts and forbids a PCIe-inclusive `value` -- "
                                         "`value` = `value_device` is that number; identical bytes: %s"
                                         % (args.steps, bool(nh == got.size and np.array_equal(out_h[:nh], got))))
+            # rank 0's range opens the stream, so a whole-block prefix of it is a prefix of the WHOLE stream at any N, and the
+            # .zlng of a whole-block prefix is a prefix of the stream's .zlng (state only flows forward)
             sample_n = min(n, (args.cpu_sample_mib << 20) // BLOCK * BLOCK) or n
             cpu, kind = cpu_encoder()
             t1 = time.perf_counter(); z = cpu.encode(x[:sample_n], args.level); tc = time.perf_counter() - t1
-            # the .zlng of a whole-block prefix is a prefix of the stream's .zlng (state only flows forward)
-            res["parity"] = bool(np.array_equal(got[: z.size], z))
-            res["cpu_baseline"] = {"value": round(sample_n / tc / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": kind,
-                                   "sample": "first %d MiB of the same stream, e%d, single thread, "
-                                             "GPU output prefix compared byte-for-byte" % (sample_n >> 20, args.level)}
+            prefix_ok = bool(z.size <= got.size and np.array_equal(got[: z.size], z))
+            res["cpu_baseline"] = {"value": round(sample_n / tc / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": kind, "cpu": cpu_model(),
+                                   "sample": "first %d MiB of the %sstream, e%d, single thread, rank 0's "
+                                             "GPU output prefix compared byte-for-byte: %s" % (sample_n >> 20, "whole sharded " if single else "same ", args.level, prefix_ok)}
+            if not args.no_multistream:
+                res["cpu_baseline_multistream"] = cpu_multistream(args.level)
             hot = enc.streams[-1].debug_fetch(8, 0, np.uint32, 256)
             if len(enc.parts) == 1 and args.level == 0:
                 res["rank_chain"] = rank_chain_line(x, args.level, int(hot.max()), stage.get("mtf_chain", 0.0))
+        # parity: every check that ran must have passed, and at least one must have run
+        checks = [c for c in (ranges_ok, prefix_ok) if c is not None]
+        res["parity"] = bool(checks and all(checks)) if checks else None
         if not args.no_cpu_baseline and world == 1 and len(enc.parts) == 1 and args.level == 0:
             res["alt_host_rank_chains"] = alt_host_rank(args, local, nb, d_in, n, d_out, cap, d_state, d_state0, init_level, got)
         if not args.no_cpu_baseline and not args.no_realtext and world == 1 and args.size == 1_000_000_000:
             res.update(realtext_workload(args, local))
         if alt_multi is not None:
             res["alt_host_rank_chains"] = alt_multi
-        res["zlng_sha256_rank0"] = hashlib.sha256(got.tobytes()).hexdigest()
+        res["zlng_sha256_rank0"] = per_rank[0][1]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

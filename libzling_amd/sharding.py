@@ -56,7 +56,7 @@ class RangeEncoder:
                                          concatenation of its segments, not one run)
     """
 
-    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=3, stagger=None, parts=None):
+    def __init__(self, make_stream, nblocks, ctx_blocks=128, parses_in_flight=2, stagger=None, parts=None):
         self.parts = list(parts) if parts else split_blocks(nblocks, ctx_blocks)     # parts: explicit block counts of the contexts
         assert sum(self.parts) == nblocks and all(0 < p <= 240 for p in self.parts)
         self.streams = [make_stream(p) for p in self.parts]
@@ -65,7 +65,8 @@ class RangeEncoder:
         # starts when context k's has finished: parses END in stream order, and the rank stage of context k -- which has to wait
         # for the tables context k - 1 leaves -- runs beside the parse of context k + 1 (schedule_model below is the arithmetic)
         self.parses_in_flight = parses_in_flight
-        # stagger = (first, gap_s) or "auto": launches spread in TIME, which no dependency between parses can express -- the first
+        # stagger = (first, gap_s), ("at", [t_s per context]) or "auto" -- SECONDS here (time.sleep); schedule_model* below takes the
+        # same shapes in MILLISECONDS (it adds them to stage times, which the library reports in ms).  Launches spread in TIME, which no dependency between parses can express -- the first
         # `first` contexts are queued at once, context k (k - first + 1) * gap_s seconds later by a helper thread.  With one context
         # first and one more per rank-stage duration ("auto": gap = the rank stage's measured time per block, 10.4 ms before anything
         # was measured, times the context's blocks) few blocks are in flight at the start, so the first parse ends early and the
@@ -97,21 +98,31 @@ class RangeEncoder:
             plan = self.stagger_plan()
             if plan[0] == "at":                          # explicit launch times (seconds into the step), one per context
                 at = list(plan[1])
-                first = sum(1 for t in at if t <= 0.0)
+                if len(at) != len(jobs):
+                    raise ValueError("stagger ('at', times): %d launch times for %d contexts" % (len(at), len(jobs)))
             else:
                 first, gap = plan
                 at = [0.0 if k < first else (k - first + 1) * gap for k in range(len(jobs))]
+            now = [j for j in jobs if at[j[0]] <= 0.0]                       # per context, wherever it stands in the range
+            later = sorted((j for j in jobs if at[j[0]] > 0.0), key=lambda j: at[j[0]])
             self._queued = [threading.Event() for _ in jobs]
+            self._late_error = None
             t0 = time.perf_counter()
 
             def late():
-                for k, s, ptr, n in jobs[first:]:
-                    d = t0 + at[k] - time.perf_counter()
-                    if d > 0:
-                        time.sleep(d)
-                    s.parse_device(ptr, n)
-                    self._queued[k].set()
-            for k, s, ptr, n in jobs[:first]:
+                try:
+                    for k, s, ptr, n in later:
+                        d = t0 + at[k] - time.perf_counter()
+                        if d > 0:
+                            time.sleep(d)
+                        s.parse_device(ptr, n)
+                        self._queued[k].set()
+                except BaseException as e:               # finish() must not wait for a parse that will never be queued
+                    self._late_error = e
+                finally:
+                    for ev in self._queued:
+                        ev.set()
+            for k, s, ptr, n in now:
                 s.parse_device(ptr, n)
                 self._queued[k].set()
             self._late = threading.Thread(target=late, daemon=True)
@@ -136,6 +147,9 @@ class RangeEncoder:
         for k, s in enumerate(self.streams):
             if self._queued:
                 self._queued[k].wait()                     # (the helper thread of a staggered schedule has queued this context's parse)
+                if getattr(self, "_late_error", None) is not None:
+                    err, self._late_error = self._late_error, None
+                    raise RuntimeError("a staggered parse could not be queued (context %d or later of this range)" % k) from err
             s.set_state_device(d_state, level)
             n = s.finish_device(d_out + pos, cap - pos)
             level = s.get_state_device(d_state)
@@ -192,8 +206,9 @@ def schedule_model(stages, parses_in_flight=2, stagger=None):
 def schedule_model_ranks(per_rank_stages, parses_in_flight=2, stagger=None):
     """The same for a stream sharded over ranks: every rank parses its own contexts on its own GPU (all ranks start together),
     and the finishes follow one another in STREAM order across the ranks -- rank r's first context waits for rank r - 1's last
-    (the 64 KiB state hand-off).  per_rank_stages[r] = [(parse, rank, huffman)] of rank r's contexts.  stagger = (first, gap_ms):
-    context k of a rank is queued (k - first + 1) * gap_ms after the step began (k >= first) instead of behind another parse."""
+    (the 64 KiB state hand-off).  per_rank_stages[r] = [(parse, rank, huffman)] of rank r's contexts, in MILLISECONDS.  stagger =
+    (first, gap_ms): context k of a rank is queued (k - first + 1) * gap_ms after the step began (k >= first) instead of behind
+    another parse; ("at", [ms per context]): explicit launch times.  (RangeEncoder takes the same shapes in SECONDS.)"""
     prev = 0.0
     for stages in per_rank_stages:
         parse_end = []

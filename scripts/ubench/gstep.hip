@@ -81,6 +81,47 @@
     "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t" \
     "v_cndmask_b32_sdwa %[tf], %[" #PK "], %[tf], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
     "s_cselect_b64 exec, exec, 0\n\t"
+// Round 5 (gfx940/950 owe TWO wait states between a VALU write of VCC and a VALU read of it -- LLVM's hazard recognizer
+// pads a plain v_cmp; v_cndmask with s_nop 0 on gfx950 -- and G6D has one, the late branch):
+// G7N: G6D with an s_nop 0 behind the late branch (seven slots)
+#define G7N(PK, B) \
+    "v_cmp_ne_u32_sdwa vcc, %[" #PK "], %[tf] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "s_cbranch_scc0 9f\n\t" \
+    "s_nop 0\n\t" \
+    "v_cndmask_b32_dpp %[tf], %[tf], %[tf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_ashr_i64 vcc, vcc, 1\n\t" \
+    "v_cndmask_b32_sdwa %[tf], %[" #PK "], %[tf], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t"
+// G7M: the s_nop in front of the branch
+#define G7M(PK, B) \
+    "v_cmp_ne_u32_sdwa vcc, %[" #PK "], %[tf] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "s_nop 0\n\t" \
+    "s_cbranch_scc0 9f\n\t" \
+    "v_cndmask_b32_dpp %[tf], %[tf], %[tf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_ashr_i64 vcc, vcc, 1\n\t" \
+    "v_cndmask_b32_sdwa %[tf], %[" #PK "], %[tf], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, vcc\n\t"
+// H6: six slots WITH two instructions between the compare and the DPP select.  The shifted mask goes to its own SGPR pair
+// (s_ashr_i64 s[92:93], vcc, 1), so the next compare does not overwrite it and the test of step K - 1 moves BEHIND the compare
+// of step K, next to its branch: cmp(K), test(K-1), branch(K-1), dpp(K), ashr(K), select(K).  The second select is then a VOP3
+// v_cndmask with an explicit mask, which cannot take an SDWA byte: the literal must be a whole dword of a vector register
+// (sixteen wave-uniform dwordx4 loads per tile instead of four).
+#define H6(L) \
+    "v_cmp_ne_u32_e32 vcc, %[" #L "], %[tf]\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, s[92:93]\n\t" \
+    "s_cbranch_scc0 9f\n\t" \
+    "v_cndmask_b32_dpp %[tf], %[tf], %[tf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_ashr_i64 s[92:93], vcc, 1\n\t" \
+    "v_cndmask_b32_e64 %[tf], %[" #L "], %[tf], s[92:93]\n\t"
+// H6B: the test one slot earlier in the NEXT step is not possible (it needs ashr(K)); variant with branch first, then test of the
+// step before it is what G6D does.  H6N: H6 with the test and the branch swapped against each other's step (branch(K-2) ahead of test(K-1))
+#define H6N(L) \
+    "v_cmp_ne_u32_e32 vcc, %[" #L "], %[tf]\n\t" \
+    "s_cbranch_scc0 9f\n\t" \
+    "s_andn2_b64 s[90:91], 0x1fffff, s[92:93]\n\t" \
+    "v_cndmask_b32_dpp %[tf], %[tf], %[tf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_ashr_i64 s[92:93], vcc, 1\n\t" \
+    "v_cndmask_b32_e64 %[tf], %[" #L "], %[tf], s[92:93]\n\t"
 #define W4(S, PK) S(PK, 0) S(PK, 1) S(PK, 2) S(PK, 3)
 #define TILE(S) W4(S, p0) W4(S, p1) W4(S, p2) W4(S, p3) W4(S, p4) W4(S, p5) W4(S, p6) W4(S, p7) W4(S, p8) W4(S, p9) W4(S, p10) W4(S, p11) W4(S, p12) W4(S, p13) W4(S, p14) W4(S, p15)
 typedef unsigned Tile16 __attribute__((ext_vector_type(16)));
@@ -131,6 +172,37 @@ typedef unsigned V4 __attribute__((ext_vector_type(4)));
         if (threadIdx.x == 0) *cyc = __builtin_readcyclecounter() - t0;                                                    \
         out[threadIdx.x] = tf;                                                                                             \
     }
+// dword-literal form (H6): sixteen wave-uniform dwordx4 loads per tile, the NEXT tile's while this one runs
+#define D4(S, Q) S(Q##0) S(Q##1) S(Q##2) S(Q##3)
+#define TILE_D(S) D4(S, a) D4(S, b) D4(S, c) D4(S, d) D4(S, e) D4(S, f) D4(S, g) D4(S, h) D4(S, i) D4(S, j) D4(S, k) D4(S, l) D4(S, m) D4(S, n) D4(S, o) D4(S, p)
+#define DOP(Q, V) [Q##0] "v"(V[0]), [Q##1] "v"(V[1]), [Q##2] "v"(V[2]), [Q##3] "v"(V[3])
+#define KERNEL_D(NAME, S)                                                                                                  \
+    __global__ void NAME(const unsigned* lit, unsigned* out, unsigned long long* cyc) {                                    \
+        const unsigned ln = threadIdx.x - 1;                                                                               \
+        unsigned tf = ln <= 20u ? 65 + ln : 0x100 + threadIdx.x;                                                            \
+        V4 A[16], B[16];                                                                                                   \
+        const V4* q = (const V4*)lit;                                                                                      \
+        for (int t = 0; t < 16; t++) A[t] = q[t];                                                                          \
+        const unsigned long long t0 = __builtin_readcyclecounter();                                                        \
+        asm volatile("s_mov_b64 exec, -2\n\ts_mov_b64 s[92:93], 0" ::: "s92", "s93");                                      \
+        for (unsigned base = 0; base < NLIT; base += 64) {                                                                 \
+            const V4* nq = (const V4*)(lit + base + 64);                                                                   \
+            for (int t = 0; t < 16; t++) B[t] = nq[t];                                                                     \
+            asm volatile("s_cmp_eq_u32 0, 0\n\t" TILE_D(S) "9:\n\t"                                                       \
+                         : [tf] "+v"(tf)                                                                                   \
+                         : DOP(a, A[0]), DOP(b, A[1]), DOP(c, A[2]), DOP(d, A[3]), DOP(e, A[4]), DOP(f, A[5]), DOP(g, A[6]), DOP(h, A[7]), \
+                           DOP(i, A[8]), DOP(j, A[9]), DOP(k, A[10]), DOP(l, A[11]), DOP(m, A[12]), DOP(n, A[13]), DOP(o, A[14]), DOP(p, A[15]) \
+                         : "vcc", "scc", "s90", "s91", "s92", "s93");                                                      \
+            for (int t = 0; t < 16; t++) A[t] = B[t];                                                                      \
+        }                                                                                                                  \
+        asm volatile("s_mov_b64 exec, -1");                                                                                \
+        if (threadIdx.x == 0) *cyc = __builtin_readcyclecounter() - t0;                                                    \
+        out[threadIdx.x] = tf;                                                                                             \
+    }
+KERNEL_D(k_h6, H6)
+KERNEL_D(k_h6n, H6N)
+KERNEL_V(k_g7n, G7N, "s_cmp_eq_u32 0, 0\n\t", 1, ~1ull)
+KERNEL_V(k_g7m, G7M, "s_cmp_eq_u32 0, 0\n\t", 1, ~1ull)
 KERNEL_S(k_f5, F5, "")
 KERNEL_V(k_g4n, G4N, "", 0, ~0ull)
 KERNEL_V(k_g4, G4, "", 0, ~0ull)
@@ -174,7 +246,27 @@ int main() {
         hipMemcpy(out, d_out, 256, hipMemcpyDeviceToHost);
         printf("DPPX: lane 1 reads an EXEC-disabled lane 0 through wave_shr:1 -> %u (111 = write suppressed, 500 = read anyway, 0 = zero)  lane 2 -> %u (expect 111)\n", out[1], out[2]);
     }
+    std::vector<unsigned> lit32(NLIT + 256);
+    for (int i = 0; i < NLIT + 256; i++) lit32[i] = lit[i];
+    unsigned* d_lit32; hipMalloc(&d_lit32, (NLIT + 512) * 4);
+    hipMemcpy(d_lit32, lit32.data(), (NLIT + 256) * 4, hipMemcpyHostToDevice);
+    struct { const char* name; void (*k)(const unsigned*, unsigned*, unsigned long long*); } kd[] = {
+        {"H6  (cmp, test K-1, branch K-1, dpp, ashr->s[92:93], vop3 select; dword literals)", k_h6},
+        {"H6N (cmp, branch K-2, test K-1, dpp, ashr, vop3 select; dword literals)", k_h6n}};
+    for (auto& kk : kd) {
+        unsigned out[64]; unsigned long long cyc = 0;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(kk.k, dim3(1), dim3(64), 0, 0, d_lit32, d_out, d_cyc);
+        hipDeviceSynchronize();
+        hipEventRecord(e0); hipLaunchKernelGGL(kk.k, dim3(1), dim3(64), 0, 0, d_lit32, d_out, d_cyc); hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpy(out, d_out, 256, hipMemcpyDeviceToHost); hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost);
+        int bad = 0; for (int i = 0; i < 21; i++) bad += out[i + 1] != ref[i];
+        printf("%-84s %6.2f ns per literal  %5.1f cycles  table %s\n", kk.name, ms * 1e6 / NLIT, (double)cyc / NLIT, bad ? "WRONG" : "ok");
+    }
     struct { const char* name; void (*k)(const unsigned char*, unsigned*, unsigned long long*); int shift; } ks[] = {
+        {"G7N (G6D + s_nop 0 behind the late branch)", k_g7n, 1}, {"G7M (G6D + s_nop 0 in front of the late branch)", k_g7m, 1},
         {"F5  (5 VALU + s_nop, test-free)", k_f5, 0}, {"G4N (cmp, nop, dpp sel, s_ashr, sdwa sel)", k_g4n, 0}, {"G4  (the same, no s_nop)", k_g4, 0},
         {"G6A (G4 + s_andn2 + branch in the step)", k_g6a, 0}, {"G6B (lane 0 off, test on shifted mask, late branch)", k_g6b, 1},
         {"G6C (cmp, dpp, ashr, test, sdwa, branch)", k_g6c, 1}, {"G6D (cmp, branch, dpp, ashr, sdwa, test)", k_g6d, 1}, {"G6E (G6C with s_cselect exec instead of the branch)", k_g6e, 1},

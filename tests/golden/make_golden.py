@@ -70,16 +70,73 @@ def config_streams():
     json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
 
 
+def block_ends(z):
+    """Offset behind every block of a .zlng stream (Appendix A: a block is its sub-blocks followed by one 0x00)."""
+    ends, p, n = [], 0, len(z)
+    while p < n:
+        if z[p] == 0:
+            p += 1
+            ends.append(p)
+            continue
+        p += 13 + int.from_bytes(z[p + 9: p + 13].tobytes(), "big")
+    assert p == n and (n == 0 or ends[-1] == n)
+    return ends
+
+
+def sharded_ranges():
+    """What every rank of `bench.py --gpus N` must produce, from the REAL reference: one stream of N x 10^9 bytes (weak, the
+    driver's scaling runs) resp. 10^9 bytes (--strong), split by libzling_amd.sharding.plan into contiguous block ranges.  The
+    .zlng of a block range is the slice of the reference's stream between the block ends that bound it (the reference never
+    starts a block's bytes before it has pushed the previous block's terminator, src/libzling.cpp:187-284).  Pins size + SHA-256
+    per rank for N = 1, 2, 4, 8 (and 3, which the one-device control-flow test runs); about 3 minutes of one host core and
+    11 GB of memory.  The weak streams are prefixes of one another up to the last, ragged block of each, so each N is run whole."""
+    import hashlib
+    from oracle_py import textgen
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from libzling_amd import sharding
+    man = json.load(open(os.path.join(HERE, "manifest.json")))
+    ref = Reference()
+    per = 1_000_000_000
+    out = {"what": "per-rank .zlng of bench.py's sharded streams at e0 (textgen chunk 0 onwards), sharding.plan ranges",
+           "provenance": "the REAL reference (oracle/_ref) over each whole stream in this container, sliced at its block ends: tests/golden/make_golden.py --ranges",
+           "per_gpu_bytes": per, "level": 0, "weak": {}, "strong": {}}
+
+    def pins(z, ranges):
+        ends = [0] + block_ends(z)
+        res = []
+        for off, n in ranges:
+            b0, b1 = off // corpus.BLOCK, (off + n + corpus.BLOCK - 1) // corpus.BLOCK
+            seg = z[ends[b0]: ends[b1]]
+            res.append({"offset": int(off), "bytes": int(n), "zlng_bytes": int(seg.size), "sha256": hashlib.sha256(seg.tobytes()).hexdigest()})
+        assert sum(r["zlng_bytes"] for r in res) == z.size
+        return res
+    for world in (1, 2, 3, 4, 8):
+        x = textgen(per * world, 0)
+        z = ref.encode(x, 0)
+        out["weak"][str(world)] = {"stream_bytes": int(x.size), "zlng_bytes": int(z.size), "sha256": hashlib.sha256(z.tobytes()).hexdigest(),
+                                   "ranks": pins(z, sharding.plan(per * world, world, per_rank_bytes=per))}
+        print("weak", world, z.size, out["weak"][str(world)]["sha256"], flush=True)
+        if world == 1:
+            assert out["weak"]["1"]["sha256"] == man["config3_enwik9_shape"]["sha256"]
+            for w in (2, 3, 4, 8):
+                out["strong"][str(w)] = {"stream_bytes": per, "zlng_bytes": int(z.size), "ranks": pins(z, sharding.plan(per, w))}
+        del x, z
+    man["sharded_ranges"] = out
+    json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+
+
 def main():
     if "--config4" in sys.argv:
         return config4_share()
+    if "--ranges" in sys.argv:
+        return sharded_ranges()
     if "--configs" in sys.argv:
         return config_streams()
     ref = Reference()
     man = {"inputs": {}, "streams": {}, "rolz": {}}
     try:
         old = json.load(open(os.path.join(HERE, "manifest.json")))
-        for k in ("config4_share", "config12_enwik8_shape", "config3_enwik9_shape"):      # expensive: kept unless --config4 / --configs
+        for k in ("config4_share", "config12_enwik8_shape", "config3_enwik9_shape", "sharded_ranges"):      # expensive: kept unless --config4 / --configs / --ranges
             if k in old:
                 man[k] = old[k]
     except Exception:

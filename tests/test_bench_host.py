@@ -85,3 +85,62 @@ def test_schedule_model_with_explicit_launch_times():
     st = [(1500.0, 600.0, 0.0), (2000.0, 1300.0, 0.0), (2000.0, 1300.0, 0.0)]
     # parses end 1500, 300 + 2000, 1300 + 2000; finishes 2100, 3600, 4900
     assert sharding.schedule_model(st, 2, ("at", [0.0, 300.0, 1300.0])) == 4900.0
+
+
+def test_block_ends_and_expected_ranges_slice_the_cpu_stream_at_block_ends(oracle, monkeypatch):
+    """bench.py's PASS/FAIL column at N > 1: the bytes a rank must produce are the slice of the whole stream's .zlng between
+    the block ends that bound its range (here with 64 KiB "blocks" so that the CPU suite stays fast)."""
+    import hashlib
+    import numpy as np
+    from oracle_py import textgen
+    x = textgen(200_000, 5)
+    z = oracle.encode(x, 0)
+    ends = bench.zlng_block_ends(z)
+    assert ends == [z.size]                                         # one block: one terminator, at the very end
+    z2 = np.concatenate([z, z])                                     # two framed blocks back to back walk as two
+    assert bench.zlng_block_ends(z2) == [z.size, 2 * z.size]
+
+    class A:                                                        # the argparse fields expected_ranges reads
+        level, strong, size, no_cpu_baseline = 0, False, 200_000, False
+    monkeypatch.setattr(bench, "load_input", lambda n, c: (x[:n], "synthetic"))
+    monkeypatch.setattr(bench, "cpu_encoder", lambda: (oracle, "port"))
+    want, src = bench.expected_ranges(A, 1, False, "synthetic", [(0, 200_000)], 1 << 30)
+    assert want == [(int(z.size), hashlib.sha256(z.tobytes()).hexdigest())] and src.startswith("port-live")
+    assert bench.expected_ranges(A, 1, False, "synthetic", [(0, 200_000)], 1000)[0] is None        # above the live limit
+    A.no_cpu_baseline = True
+    assert bench.expected_ranges(A, 1, False, "synthetic", [(0, 200_000)], 1 << 30)[0] is None
+
+
+def test_pinned_ranges_cover_the_driver_scaling_runs(manifest):
+    """tests/golden/manifest.json `sharded_ranges`: the per-rank size + SHA-256 of bench.py --gpus N for N = 1, 2, 4, 8 (weak: N x
+    10^9 bytes; strong: 10^9 bytes), from the REAL reference; the ranges are sharding.plan's and the slices add up."""
+    from libzling_amd import sharding
+    pins = manifest["sharded_ranges"]
+    per = pins["per_gpu_bytes"]
+    assert per == 1_000_000_000 and pins["level"] == 0
+    for w in (1, 2, 3, 4, 8):
+        e = pins["weak"][str(w)]
+        assert [(r["offset"], r["bytes"]) for r in e["ranks"]] == sharding.plan(per * w, w, per_rank_bytes=per)
+        assert sum(r["zlng_bytes"] for r in e["ranks"]) == e["zlng_bytes"] and len(e["sha256"]) == 64
+    assert pins["weak"]["1"]["sha256"] == manifest["config3_enwik9_shape"]["sha256"]
+    for w in (2, 3, 4, 8):
+        e = pins["strong"][str(w)]
+        assert [(r["offset"], r["bytes"]) for r in e["ranks"]] == sharding.plan(per, w)
+        assert sum(r["zlng_bytes"] for r in e["ranks"]) == manifest["config3_enwik9_shape"]["zlng_bytes"]
+    # the weak streams are prefixes of one another: rank 0's range (60 whole blocks) has the same bytes at every N > 1
+    assert len({pins["weak"][str(w)]["ranks"][0]["sha256"] for w in (2, 3, 4, 8)}) == 1
+
+
+def test_expected_ranges_uses_the_pins_for_the_driver_configuration(manifest):
+    class A:
+        level, strong, size, no_cpu_baseline = 0, False, 1_000_000_000, True
+    from libzling_amd import sharding
+    for w in (1, 2, 4, 8):
+        rg = sharding.plan(A.size * w, w, per_rank_bytes=A.size) if w > 1 else [(0, A.size)]
+        want, src = bench.expected_ranges(A, w, w > 1, "synthetic", rg, 0)
+        assert src.startswith("pins") and len(want) == w
+        assert want == [(r["zlng_bytes"], r["sha256"]) for r in manifest["sharded_ranges"]["weak"][str(w)]["ranks"]]
+    A.strong = True
+    want, src = bench.expected_ranges(A, 4, True, "synthetic", sharding.plan(A.size, 4), 0)
+    assert src.startswith("pins") and sum(k for k, _ in want) == manifest["config3_enwik9_shape"]["zlng_bytes"]
+    assert bench.expected_ranges(A, 4, True, "enwik9", sharding.plan(A.size, 4), 0)[0] is None      # a real file has no pins

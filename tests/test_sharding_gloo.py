@@ -204,3 +204,68 @@ def test_range_encoder_orders_the_parses_of_its_contexts():
             if (k, k - pif) in want:
                 assert log.index(("after", k, k - pif)) + 1 == [i for i, e in enumerate(log) if e[0] == "parse" and e[1] == k][0]
         assert sum(b for kind, a, b in log if kind == "parse") == 50 * BLOCK - 123
+
+
+class _LogStream:
+    """A stream that only logs (and can be told to fail its parse), with the finish-side methods RangeEncoder calls."""
+
+    def __init__(self, ix, log, fail=False):
+        self.ix, self.log, self.fail = ix, log, fail
+
+    def parse_device(self, ptr, n):
+        if self.fail:
+            raise RuntimeError("ZLNG_E_NOMEM (made up)")
+        self.log.append(("parse", self.ix))
+
+    def set_state_device(self, d_state, level):
+        pass
+
+    def finish_device(self, d_out, cap):
+        self.log.append(("finish", self.ix))
+        return 8
+
+    def get_state_device(self, d_state):
+        return 0
+
+    def close(self):
+        pass
+
+
+def test_staggered_parse_that_fails_on_the_helper_thread_surfaces_in_finish_instead_of_hanging():
+    """the helper thread of a staggered schedule died silently when a late parse raised, and finish() then waited for
+    its event forever (on several GPUs: every later rank hung in the hand-off).  Now the error is kept, every event is set and
+    finish() re-raises it at the context that lacks its parse."""
+    import threading
+    log, made = [], []
+    enc = sharding.RangeEncoder(lambda blocks: made.append(_LogStream(len(made), log, fail=(len(made) == 2))) or made[-1], 40, 10,
+                                stagger=(1, 0.01))
+    enc.parse(1 << 40, 40 * BLOCK)
+    res = {}
+
+    def run():
+        try:
+            enc.finish(1 << 41, 1 << 30, 1 << 42, 0)
+        except Exception as e:
+            res["err"] = e
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(10.0)
+    assert not t.is_alive(), "finish() hangs behind a parse that was never queued"
+    assert isinstance(res.get("err"), RuntimeError) and "ZLNG_E_NOMEM" in str(res["err"].__cause__)
+    assert ("finish", 0) in log and ("finish", 1) in log and ("finish", 2) not in log      # what was parsed still finishes in order
+    enc.close()
+
+
+def test_staggered_launch_times_need_not_be_a_zero_prefix_and_must_match_the_contexts():
+    """('at', times): a context is launched at once iff ITS time is <= 0, wherever it stands in the range; a list of the wrong
+    length is an error at parse(), not an IndexError on the helper thread."""
+    log, made = [], []
+    enc = sharding.RangeEncoder(lambda blocks: made.append(_LogStream(len(made), log)) or made[-1], 30, 10, stagger=("at", [0.05, 0.0, 0.02]))
+    enc.parse(1 << 40, 30 * BLOCK)
+    assert log == [("parse", 1)]                                    # only context 1 is due at t = 0
+    segs, _lv = enc.finish(1 << 41, 1 << 30, 1 << 42, 0)
+    assert [e for e in log if e[0] == "parse"] == [("parse", 1), ("parse", 2), ("parse", 0)] and len(segs) == 3
+    enc.close()
+    bad = sharding.RangeEncoder(lambda blocks: _LogStream(0, log), 30, 10, stagger=("at", [0.0, 0.1]))
+    with pytest.raises(ValueError):
+        bad.parse(1 << 40, 30 * BLOCK)
