@@ -18,6 +18,10 @@
 namespace zlng {
 
 // ------------------------------------------------------------------------------ K7 frame walk
+// Errors are met in STREAM order, like the reference's one loop (src/libzling.cpp:312-404): a sub-block's Huffman stream and
+// replay come before the flag and sizes of the sub-block behind it.  So a framing error inside a block does not hide what is in
+// front of it: the sub-blocks up to it are kept as a PROBE block -- decoded and replayed like any other; if one of them fails, that
+// is the call's error; if they all pass, the framing error (`pending`) is.  A probe block is never reported as output.
 __global__ __launch_bounds__(64) void k_frame_walk(DecodeArgs a) {
     if (threadIdx.x != 0) return;
     const uint8_t* z = a.z;
@@ -26,28 +30,44 @@ __global__ __launch_bounds__(64) void k_frame_walk(DecodeArgs a) {
     uint32_t nblk = 0, nsub = 0, err = 0;
     while (p < n && nblk < a.max_blocks && !err) {
         const uint32_t first_sub = nsub;
-        uint32_t last_encpos = 0;
-        bool closed = false;
+        const uint64_t first_tok = tok_total;
+        uint32_t last_encpos = 0, pending = 0;
+        bool closed = false, too_many = false;
         while (p < n) {
             const uint32_t flag = z[p++];
-            if (flag != 0 && flag != 1) { err = (uint32_t)(-ZLNG_DEC_E_FLAG); break; }
+            if (flag != 0 && flag != 1) { pending = (uint32_t)(-ZLNG_DEC_E_FLAG); break; }               // src/libzling.cpp:315-317
             if (flag == 0) { closed = true; break; }
             if (p + 12 > n) break;                                   // header cut: block incomplete
             auto be32 = [&](uint64_t o) { return (uint32_t)z[o] << 24 | (uint32_t)z[o + 1] << 16 | (uint32_t)z[o + 2] << 8 | z[o + 3]; };
             const uint32_t encpos = be32(p), rlen = be32(p + 4), olen = be32(p + 8);
             p += 12;
-            if (rlen > (uint32_t)kSubSyms || olen > (uint32_t)kPayloadMax) { err = (uint32_t)(-ZLNG_DEC_E_BLOCKSIZE); break; }
-            if (olen < (uint32_t)kTableBytes || encpos > (uint32_t)kBlockIn || encpos < last_encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+            if (rlen > (uint32_t)kSubSyms || olen > (uint32_t)kPayloadMax) { pending = (uint32_t)(-ZLNG_DEC_E_BLOCKSIZE); break; }   // :326-328
+            // a payload shorter than its own length tables: the reference would take the missing table bytes from whatever its
+            // buffer held (:347-356); rejected
+            if (olen < (uint32_t)kTableBytes) { pending = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
             if (p + olen > n) break;                                 // payload cut: block incomplete
-            if (nsub >= a.max_subs) { err = (uint32_t)(-ZLNG_DEC_E_LIMIT); break; }
-            if (tok_total + rlen > a.tok_cap || out_total + encpos > a.out_cap) { err = (uint32_t)(-ZLNG_DEC_E_LIMIT); break; }
-            a.subs[nsub] = DecSub{p, tok_total, encpos, rlen, olen, nblk};
-            nsub++;
-            tok_total += rlen;
+            // every u16 entry stands for at least one output byte, so a block with more entries than 16 Mi cannot land on its
+            // encpos: the replay of an earlier sub-block fails first (lzdecode failed) -- the walk goes on only to see whether the
+            // block is complete, and records nothing more
+            if (!too_many && (tok_total - first_tok) + rlen > (uint64_t)kTokCapMax + 64) too_many = true;
+            if (!too_many) {
+                if (nsub >= a.max_subs) { err = (uint32_t)(-ZLNG_DEC_E_LIMIT); break; }
+                // (an encpos beyond the block size fails in the replay, behind the sub-block's Huffman checks; it reserves no output)
+                if (tok_total + rlen > a.tok_cap || (encpos <= (uint32_t)kBlockIn && out_total + encpos > a.out_cap)) { err = (uint32_t)(-ZLNG_DEC_E_LIMIT); break; }
+                a.subs[nsub] = DecSub{p, tok_total, encpos, rlen, olen, nblk};
+                nsub++;
+                tok_total += rlen;
+                last_encpos = encpos;
+            }
             p += olen;
-            last_encpos = encpos;
         }
-        if (err || !closed) { nsub = first_sub; break; }             // drop the incomplete block
+        if (err || !(closed || pending)) { nsub = first_sub; break; }  // a resource limit, or the input ends inside the block: dropped
+        if (too_many) pending = (uint32_t)(-ZLNG_DEC_E_LZ);
+        if (pending) {
+            err = pending;
+            if (nsub > first_sub) { a.blocks[nblk] = DecBlock{first_sub, nsub - first_sub, out_total, 0, pending, p}; nblk++; }
+            break;
+        }
         a.blocks[nblk] = DecBlock{first_sub, nsub - first_sub, out_total, last_encpos, 0, p};
         out_total += last_encpos;
         nblk++;
@@ -68,17 +88,54 @@ __global__ __launch_bounds__(64) void k_frame_walk(DecodeArgs a) {
 // holds dword l; the next window is already in flight) while the symbol loop runs wave-uniformly.
 constexpr int kLut1Bits = kMaxLen1, kLut2Bits = kMaxLen2;
 
-__device__ void build_codes_lane0(const uint8_t* len, uint16_t* code, int n, int limit) {   // src/libzling_huffman.cpp:114-138
+// Per alphabet, for the exact table build below: symbols of every length in symbol order (`sorted`, lengths ascending), where each
+// length's run starts (`off`), how many it holds (`cnt`) and the canonical code of its first symbol (`start`, not reduced mod 2^l).
+struct LenClasses { uint32_t off[16], cnt[16], start[16]; };
+
+// Returns true when the length set is OVER-SUBSCRIBED (Kraft sum above one): codes then collide in the decode table, and which
+// symbol an entry ends up with is defined by the reference's fill ORDER (below).
+__device__ bool build_codes_lane0(const uint8_t* len, uint16_t* code, int n, int limit, LenClasses* lc, uint16_t* sorted) {   // src/libzling_huffman.cpp:114-138
     uint32_t next[16];
     uint32_t count[16];
     for (int l = 0; l < 16; l++) count[l] = 0;
     for (int i = 0; i < n; i++) count[len[i]]++;
-    uint32_t c = 0;
-    for (int l = 1; l <= limit; l++) { next[l] = c; c = (c + count[l]) * 2; }
+    uint32_t c = 0, o = 0, kraft = 0;
+    for (int l = 1; l <= limit; l++) {
+        next[l] = c; lc->start[l] = c; lc->cnt[l] = count[l]; lc->off[l] = o;
+        o += count[l];
+        kraft += count[l] << (limit - l);
+        c = (c + count[l]) * 2;
+    }
+    uint32_t fill[16];
+    for (int l = 1; l <= limit; l++) fill[l] = lc->off[l];
     for (int i = 0; i < n; i++) {
         const uint32_t l = len[i];
-        code[i] = l ? (uint16_t)((__brev(next[l]++) >> 16 & 0xFFFFu) >> (16 - l)) : (uint16_t)0;
+        // lengths above the limit (alphabet 2's nibbles go up to 15) get no code and no table entry (huffman.cpp:119-126, 146)
+        code[i] = (l && l <= (uint32_t)limit) ? (uint16_t)((__brev(next[l]++) >> 16 & 0xFFFFu) >> (16 - l)) : (uint16_t)0;
+        if (l && l <= (uint32_t)limit) sorted[fill[l]++] = (uint16_t)i;
     }
+    return kraft > (1u << limit);
+}
+
+// The decode-table entry of index i as the reference's fill leaves it (src/libzling_huffman.cpp:140-153): symbols are entered in
+// ascending order and a later one overwrites an earlier one, so an entry belongs to the LARGEST symbol whose code matches; and the
+// symbol loop asks the 2^`fast`-entry table of the codes up to `fast` bits first (src/libzling.cpp:361, 376-379), so any such code
+// beats every longer one.  A symbol of length L matches index i when its code, bit-reversed, equals i mod 2^L; the codes of one
+// length are consecutive integers from start[L] (only their low L bits survive the 16-bit reversal, huffman.cpp:128-135), so the
+// matching symbols of a length are every 2^L-th of its run and the largest is computed, not searched.
+__device__ __forceinline__ uint32_t lut_entry_exact(uint32_t i, const LenClasses& lc, const uint16_t* sorted, int limit, int fast) {
+    int best_fast = -1, best_slow = -1;
+    for (int L = 1; L <= limit; L++) {
+        const uint32_t cnt = lc.cnt[L];
+        if (!cnt) continue;
+        const uint32_t m = (1u << L) - 1u;
+        const uint32_t q = __brev(i & m) >> (32 - L);
+        const uint32_t k0 = (q - lc.start[L]) & m;
+        if (k0 >= cnt) continue;
+        const int c = (int)sorted[lc.off[L] + k0 + (((cnt - 1u - k0) >> L) << L)];
+        if (L <= fast) best_fast = c > best_fast ? c : best_fast; else best_slow = c > best_slow ? c : best_slow;
+    }
+    return best_fast >= 0 ? (uint32_t)best_fast : (best_slow >= 0 ? (uint32_t)best_slow : 0xFFFFu);
 }
 
 __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
@@ -86,6 +143,9 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
     __shared__ uint16_t lut2[1 << kLut2Bits];
     __shared__ uint8_t  len[kNsymAll + 2];
     __shared__ uint16_t code[kNsymAll];
+    __shared__ uint16_t sorted[kNsymAll];
+    __shared__ LenClasses lc1, lc2;
+    __shared__ uint32_t over[2];
     const uint32_t s = blockIdx.x;
     if (s >= (uint32_t)a.summary[3]) return;
     const DecSub sb = a.subs[s];
@@ -103,18 +163,28 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
     for (uint32_t i = lane; i < (1u << kLut2Bits); i += 64) lut2[i] = 0xFFFF;
     __syncthreads();
     if (lane == 0) {
-        build_codes_lane0(len, code, kNsym1, kMaxLen1);
-        build_codes_lane0(len + kNsym1, code + kNsym1, kNsym2, kMaxLen2);
+        over[0] = build_codes_lane0(len, code, kNsym1, kMaxLen1, &lc1, sorted);
+        over[1] = build_codes_lane0(len + kNsym1, code + kNsym1, kNsym2, kMaxLen2, &lc2, sorted + kNsym1);
     }
     __syncthreads();
-    // ZlingMakeDecodeTable (src/libzling_huffman.cpp:140-153)
-    for (uint32_t c = lane; c < (uint32_t)kNsym1; c += 64) {
-        const uint32_t l = len[c];
-        if (l > 0 && l <= (uint32_t)kLut1Bits) for (uint32_t i = code[c]; i < (1u << kLut1Bits); i += 1u << l) lut1[i] = (uint16_t)c;
+    // ZlingMakeDecodeTable (src/libzling_huffman.cpp:140-153).  A complete or under-subscribed length set gives prefix-free codes:
+    // no two symbols share a table entry and the symbols fill theirs side by side.  An over-subscribed one (hostile streams only)
+    // makes entries collide, and every entry is computed instead, as the reference's fill order and two-level lookup define it.
+    if (!over[0]) {
+        for (uint32_t c = lane; c < (uint32_t)kNsym1; c += 64) {
+            const uint32_t l = len[c];
+            if (l > 0 && l <= (uint32_t)kLut1Bits) for (uint32_t i = code[c]; i < (1u << kLut1Bits); i += 1u << l) lut1[i] = (uint16_t)c;
+        }
+    } else {
+        for (uint32_t i = lane; i < (1u << kLut1Bits); i += 64) lut1[i] = (uint16_t)lut_entry_exact(i, lc1, sorted, kMaxLen1, kMaxLen1Fast);
     }
-    for (uint32_t c = lane; c < (uint32_t)kNsym2; c += 64) {
-        const uint32_t l = len[kNsym1 + c];
-        if (l > 0 && l <= (uint32_t)kLut2Bits) for (uint32_t i = code[kNsym1 + c]; i < (1u << kLut2Bits); i += 1u << l) lut2[i] = (uint16_t)c;
+    if (!over[1]) {
+        for (uint32_t c = lane; c < (uint32_t)kNsym2; c += 64) {
+            const uint32_t l = len[kNsym1 + c];
+            if (l > 0 && l <= (uint32_t)kLut2Bits) for (uint32_t i = code[kNsym1 + c]; i < (1u << kLut2Bits); i += 1u << l) lut2[i] = (uint16_t)c;
+        }
+    } else {
+        for (uint32_t i = lane; i < (1u << kLut2Bits); i += 64) lut2[i] = (uint16_t)lut_entry_exact(i, lc2, sorted + kNsym1, kMaxLen2, kMaxLen2);
     }
     __syncthreads();
 
@@ -161,7 +231,9 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a) {
             acc >>= bl; nb -= (int)bl;
             const uint32_t base = c < 4 ? c : (c < 18 ? (2u + (c & 1u)) << ((c >> 1) - 1) : (c - 16) << 8);
             const uint32_t idx = base + ex;
-            if (idx >= (uint32_t)kRing || i + 1 >= sb.rlen) { err = (uint32_t)(-ZLNG_DEC_E_EXBITS); break; }
+            // (a match symbol in the LAST counted entry keeps its index: the reference stores it at tbuf[rlen] and its replay reads
+            //  it there, src/libzling.cpp:398, src/libzling_lz.cpp:355-356; the largest index the 32 codes name is 3840 + 255)
+            if (idx >= (uint32_t)kRing) { err = (uint32_t)(-ZLNG_DEC_E_EXBITS); break; }
             t |= idx << 16;
             i++;                                                     // a match occupies two u16 entries
         }
@@ -252,13 +324,26 @@ __global__ __launch_bounds__(64) void k_rolz_replay(DecodeArgs a) {
             const uint32_t* tok = a.tok + sb.tok_off;
             const uint32_t nt = ufl(a.sub_ntok[bk.first_sub + k]);
             if (nt & 0x80000000u) { err = nt & 0xFFFFu; break; }           // K8 rejected this sub-block's bitstream
-            if (opos + ufl(a.sub_ntok[a.max_subs + bk.first_sub + k]) != sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+            // an encpos beyond the block size: the reference's replay would write past its buffer before its size test
+            // (src/libzling_lz.cpp:363-373); rejected here, behind the Huffman checks like every replay error
+            if (sb.encpos > (uint32_t)kBlockIn) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+            // The block's two opening entries are copied as raw bytes (src/libzling_lz.cpp:327-328): a word symbol there is the byte
+            // 0 or 1 (the u16 entry truncated) and stands for ONE byte, not the two K8 counted.  A match symbol there would split
+            // its (symbol, index) pair and re-read the index as a symbol -- lengths up to 3,841 past the reference's sentinel:
+            // rejected (decoder deviations).
+            uint32_t outlen = ufl(a.sub_ntok[a.max_subs + bk.first_sub + k]);
+            for (uint32_t q = opos, t2 = 0; q < 2 && t2 < nt; q++, t2++) {
+                const uint32_t sym = ufl(tok[t2]) & 0xFFFFu;
+                if (sym >= 258u) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
+                if (sym >= 256u) outlen -= 1u;
+            }
+            if (err) break;
+            if (opos + outlen != sb.encpos) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
             for (uint32_t i = lane; i < 256; i += 64) mru[i] = 0;
             __syncthreads();
             uint32_t ti = 0;
-            while (opos < 2 && ti < nt) {                                  // first two bytes of a block are raw (src/libzling_lz.cpp:327-328)
+            while (opos < 2 && ti < nt) {
                 const uint32_t v = ufl(tok[ti++]);
-                if ((v & 0xFFFF) >= 256) { err = (uint32_t)(-ZLNG_DEC_E_LZ); break; }
                 if (lane == 0) { out[opos] = (uint8_t)v; win[opos] = (uint8_t)v; }
                 opos++;
             }
@@ -270,6 +355,7 @@ __global__ __launch_bounds__(64) void k_rolz_replay(DecodeArgs a) {
             }
             if (!err && opos != sb.encpos) err = (uint32_t)(-ZLNG_DEC_E_LZ);   // src/libzling_lz.cpp:371-373
         }
+        if (!err && bk.pad) err = bk.pad;                                  // a probe block: its sub-blocks passed, so the framing error behind them stands
         if (err && lane == 0) { a.summary[5] = b; a.summary[6] = err; }
     }
     __syncthreads();

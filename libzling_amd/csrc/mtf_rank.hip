@@ -36,16 +36,24 @@ static_assert(mtf_next_fast_ok(), "mtf_next_fast must equal int(0.95 i) / int(0.
 
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 // per-lane select by a wave-uniform 64-bit lane mask held in an SGPR pair: lane l gets (mask bit l) ? b : a.
-// (Plain C++ makes the compiler rebuild the mask test per lane with v_and + v_cmp_u64; this is one instruction.
-//  The mask comes from v_cmp / s_lshr_b64; gfx9 owes no wait states for a VALU reading such an SGPR as a constant.)
+// (Plain C++ makes the compiler rebuild the mask test per lane with v_and + v_cmp_u64; this is one instruction.)
+// gfx940 / gfx950 owe TWO wait states between a VALU that writes an SGPR or VCC (v_cmp, v_readlane, v_readfirstlane) and a VALU
+// that reads it (LLVM's hazard recognizer pads a plain v_cmp; v_cndmask with s_nop on gfx950 and not on gfx90a; it does not look
+// inside an asm statement, and these operands often come straight from a v_readlane / a ballot): the pad is part of the statement.
+// sel_k is the same select for a mask that is a compile-time constant (materialised by the scalar unit: nothing owed).
 __device__ __forceinline__ uint32_t sel(uint32_t a, uint32_t b, uint64_t mask) {
     uint32_t r;
-    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    asm volatile("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ uint32_t sel_k(uint32_t a, uint32_t b, uint64_t const_mask) {
+    uint32_t r;
+    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(const_mask));
     return r;
 }
 __device__ __forceinline__ uint32_t cvec(uint32_t uniform) {           // wave-uniform scalar as a VGPR operand
     uint32_t r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(uniform));
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(r) : "s"(uniform));
     return r;
 }
 // v[lane] = val with wave-uniform val / lane, on the slow paths only (the tile statements write lanes with constant selects).  There
@@ -217,10 +225,20 @@ constexpr uint64_t chain_allow_x() {            // bit l - 1 for every lane l wh
 }
 static_assert(chain_allow_x() == 0x3f3fff9fffffffffull, "scripts/experiments/mtf_chain_model.c prints the same mask");
 
+// ZLNG_STEP_PAD: the second of the two wait states gfx950 owes between the compare's write of VCC and the DPP select's read of it
+// (the late branch is the first).  Round 4 shipped the step without it -- a lone wavefront issues an instruction every ~5.8 cycles and
+// every soak was bit-exact -- but that rests on issue timing nobody documents; scripts/ubench/gstep.hip G7N: +0.8 ns per literal.
+// (-DZLNG_STEP_PAD_OFF builds the unpadded step for an A/B measurement; tests/test_isa_hygiene.py fails on such a build.)
+#ifdef ZLNG_STEP_PAD_OFF
+#define ZLNG_STEP_PAD
+#else
+#define ZLNG_STEP_PAD "s_nop 0\n\t"
+#endif
 #define ZLNG_C_STEP(PK, B, K, KP)                                                                               \
     "2" #K ":\n\t"                                                                                              \
     "v_cmp_ne_u32_sdwa vcc, %[" #PK "], %[tf] src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                          \
     "s_cbranch_scc0 1" #KP "f\n\t"                                                                              \
+    ZLNG_STEP_PAD                                                                                               \
     "v_cndmask_b32_dpp %[tf], %[tf], %[tf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                      \
     "s_ashr_i64 vcc, vcc, 1\n\t"                                                                                \
     "v_cndmask_b32_sdwa %[tf], %[" #PK "], %[tf], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #B " src1_sel:DWORD\n\t" \
@@ -337,6 +355,9 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
         if (a.dbg && lane == 0) { a.dbg[ctx] = 0; a.dbg[256 + ctx] = 0; }
         return;
     }
+    // The stage is one dependent chain per wavefront; whatever else is resident on its SIMD (another context's parser waves, when a
+    // range goes through several contexts) has slack by design.  Highest issue priority for the chain.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     uint8_t* st = a.state + ctx * 256;
     const int fpos = chain_pos((int)lane);                              // (folded per lane: a 64-entry constant table)
     const uint32_t padv = 0x100u | lane;                               // what lane 0 and the pads hold: no byte equals it
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
 #define ZLNG_C_SNAP(BASE)                                                                                          \
     {                                                                                                              \
         uint8_t* sp = snap + (size_t)(BASE) * 4;                                                                   \
-        sp[cpos] = (uint8_t)sel(tf, tx, padmask);                                                                  \
+        sp[cpos] = (uint8_t)sel_k(tf, tx, padmask);                                                                \
         sp[64 + lane] = (uint8_t)t1; sp[128 + lane] = (uint8_t)t2; sp[192 + lane] = (uint8_t)t3;                   \
     }
     LitQuad a0, a1, a2, a3, b0, b1, b2, b3;
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(64) void k_mtf_chain(MtfArgs a) {
     }
 #undef ZLNG_C_FULL_TILE
 #undef ZLNG_C_SNAP
-    st[cpos] = (uint8_t)sel(tf, tx, padmask);
+    st[cpos] = (uint8_t)sel_k(tf, tx, padmask);
     st[64 + lane] = (uint8_t)t1; st[128 + lane] = (uint8_t)t2; st[192 + lane] = (uint8_t)t3;
     if (a.dbg && lane == 0) { a.dbg[ctx] = __builtin_readcyclecounter() - tstart; a.dbg[256 + ctx] = n_ev; }
 }

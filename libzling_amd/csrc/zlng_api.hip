@@ -284,10 +284,11 @@ int rank_longest_chains_on_host(zlng_ctx* c, MtfArgs& ma, bool single) {
 // Rank (group by group from group g0, whose entry tables are in d_mtf), histogram and lengths of blocks [g0 * G, nb).
 int run_back(zlng_ctx* c, uint32_t nb, uint32_t g0, uint8_t* d_out, size_t out_cap) {
     const uint32_t G = rank_group_blocks(c, nb);
+    static const uint32_t chain_prio = getenv("ZLNG_CHAIN_PRIO") ? (uint32_t)atoi(getenv("ZLNG_CHAIN_PRIO")) : 1u;
     for (uint32_t b = g0 * G, g = g0; b < nb; b += G, g++) {
         const uint32_t n = std::min(G, nb - b);
         MtfArgs ma{c->d_tok + (size_t)b * c->tok_cap, c->d_ntok + b, n, c->tok_cap, c->d_mtf, c->d_tile_base, c->d_tile_hist,
-                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, nullptr, (c->d_dbg && c->max_blocks >= 22) ? c->d_dbg : nullptr};
+                   c->d_ctx_total, c->d_ctx_off, c->d_lit_byte, c->d_snap, c->d_tile_kk, nullptr, (c->d_dbg && c->max_blocks >= 22) ? c->d_dbg : nullptr, chain_prio};
         const bool single = G >= nb;                 // one group (always at level 0): time the serial chain by itself
         launch_lit_partition(ma, c->stream);
         if (single) timer_mark(c, "lit_partition");
@@ -751,7 +752,7 @@ int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size
     // Complete blocks in front of a framing error are decoded and reported first, like the reference's loop, which emits
     // every block before it throws (src/libzling.cpp:306-420); the caller meets the error at the head of its next call.
     if (nblk == 0) return sum[1] ? -(int)sum[1] : ZLNG_E_TRUNC;      // not even one complete block in the prefix
-    launch_huff_decode(da, nsub, c->stream);
+    if (nsub) launch_huff_decode(da, nsub, c->stream);               // (a prefix of empty blocks -- bare 0x00 flags -- has no sub-block at all)
     timer_mark(c, "huff_decode");
     launch_rolz_decode(da, c->stream);
     timer_mark(c, "rolz_decode");

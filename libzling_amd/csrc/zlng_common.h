@@ -16,6 +16,7 @@ constexpr int kNsym1       = 514;
 constexpr int kNsym2       = 32;
 constexpr int kNsymAll     = kNsym1 + kNsym2;   // 546: one row of freq/len/code tables
 constexpr int kMaxLen1     = 15;
+constexpr int kMaxLen1Fast = 10;        // kHuffmanMaxLen1Fast, src/libzling.cpp:67: the decoder asks a 2^10-entry table first
 constexpr int kMaxLen2     = 8;
 constexpr int kRing        = 4096;      // kBucketItemSize
 constexpr int kHashSlots   = 8192;      // kBucketItemHash

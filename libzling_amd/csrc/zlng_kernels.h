@@ -45,6 +45,7 @@ struct MtfArgs {
     uint8_t*        tile_kk;   // per tile: literals whose ranks k_mtf_replay computes from the snapshot (0 = none)
     const uint8_t*  skip;      // optional [256]: contexts k_mtf_chain leaves alone (the measured host-chain alternative, zlng_api.hip)
     unsigned long long* dbg;   // optional [512]: cycles and slow steps (literals outside the table front) per context (ZLNG_PROFILE=1 with >= 22 blocks)
+    uint32_t        prio;      // k_mtf_chain raises its wavefronts' issue priority (s_setprio 3): beside other contexts' parser waves on the same SIMD the chain wins every arbitration (ZLNG_CHAIN_PRIO=0 switches it off)
 };
 void launch_lit_partition(const MtfArgs& a, hipStream_t s);   // literals -> one dense run per context
 void launch_mtf_chain(const MtfArgs& a, hipStream_t s);       // k_mtf_chain: the serial chains

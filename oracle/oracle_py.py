@@ -36,6 +36,7 @@ class Oracle:
         L = self.lib
         L.zo_encode.argtypes = [_u8p, C.c_size_t, C.c_int, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.zo_decode.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.zo_decode_ex.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
         L.zo_encode_bound.argtypes = [C.c_size_t]
         L.zo_encode_bound.restype = C.c_size_t
         L.zo_stream_new.restype = C.c_void_p
@@ -83,6 +84,17 @@ class Oracle:
         n = C.c_size_t(0)
         rc = self.lib.zo_decode(_ptr(a) if a.size else None, a.size, _ptr(out), cap, C.byref(n))
         return rc, out[: n.value].copy()
+
+    def decode_ex(self, z, cap):
+        """(rc, bytes of the complete blocks in front of the first error, flags): flags != 0 means one of the decoder's own rules
+        for hostile streams decided or coloured the verdict (ZO_DEV_*, zlng_oracle.h) -- the reference itself would read or write
+        memory it does not own there."""
+        a = np.ascontiguousarray(np.frombuffer(bytes(z), dtype=np.uint8) if not isinstance(z, np.ndarray) else z)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n = C.c_size_t(0)
+        fl = C.c_uint32(0)
+        rc = self.lib.zo_decode_ex(_ptr(a) if a.size else None, a.size, _ptr(out), cap, C.byref(n), C.byref(fl))
+        return rc, out[: n.value].copy(), int(fl.value)
 
     # ---- stage API -------------------------------------------------------------------
     def parse_block(self, block, level=0, apply_mtf=False, stream=None):

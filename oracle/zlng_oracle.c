@@ -467,8 +467,47 @@ static void make_decode_table(const uint32_t* len, const uint16_t* code, uint16_
 
 typedef struct { uint32_t offset[ZO_RING]; uint16_t head; } zo_dbucket;   /* src/libzling_lz.h:132-135 */
 
-/* src/libzling.cpp:293-427 Decode + src/libzling_lz.cpp:318-399 ZlingRolzDecoder */
-int zo_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len) {
+/* Does the block that starts at in[ip] lie complete in the input?  Walks flags and headers only, up to the block's 0x00 or the
+ * first thing the decode loop below turns into an error by itself (a bad flag, sizes over the limits): those are met in stream
+ * order there.  0 = the input ends inside the block. */
+static int block_is_complete(const uint8_t* in, size_t n, size_t ip) {
+    for (;;) {
+        if (ip >= n) return 0;
+        const int flag = in[ip++];
+        if (flag != 1) return 1;                                        /* 0x00 closes it; anything else is an error, not a cut */
+        if (ip + 12 > n) return 0;
+        const uint32_t rlen = (uint32_t)in[ip + 4] << 24 | in[ip + 5] << 16 | in[ip + 6] << 8 | in[ip + 7];
+        const uint32_t olen = (uint32_t)in[ip + 8] << 24 | in[ip + 9] << 16 | in[ip + 10] << 8 | in[ip + 11];
+        ip += 12;
+        if (rlen > ZO_SUBBLOCK_SYMS || olen > ZO_PAYLOAD_MAX || olen < ZO_TABLE_BYTES) return 1;
+        if (ip + olen > n) return 0;
+        ip += olen;
+    }
+}
+
+/* src/libzling.cpp:293-427 Decode + src/libzling_lz.cpp:318-399 ZlingRolzDecoder.
+ *
+ * On a VALID stream this is the reference, statement by statement.  On a hostile one the reference has behaviour that no
+ * restatement can share -- it reads uninitialised or stale heap bytes, or writes past its buffers -- and there this decoder
+ * REJECTS instead (each rule sets a bit of *flags, so that the differential tests know which verdicts can be compared with the
+ * real reference and which cannot):
+ *   ZO_DEV_TRUNC     the input ends inside a block (the reference's GetChar/GetUInt32 return EOF garbage and it decodes on;
+ *                    src/libzling.cpp:312-334): ZO_E_TRUNC, before any sub-block of that block is looked at
+ *   ZO_DEV_SIGNED    rlen or olen >= 2^31 (the reference compares them as int, :326: negative values pass): ZO_E_BLOCKSIZE
+ *   ZO_DEV_SHORT     olen < 273 (the reference takes the missing table bytes from whatever obuf held, :347-356): ZO_E_LZ
+ *   ZO_DEV_ENCPOS    encpos > 16 MiB (the reference's replay would write past ibuf before its size test, lz.cpp:363-373):
+ *                    ZO_E_LZ, after the sub-block's Huffman stream has been checked like the reference checks it
+ *   ZO_DEV_OPENING   one of the two block-opening u16 entries is a match symbol (the reference copies entries as raw bytes
+ *                    there, lz.cpp:327-328, which for a two-entry match splits the pair and re-reads the index as a symbol --
+ *                    lengths up to 3,841 past the buffer's sentinel): ZO_E_LZ
+ *   ZO_DEV_SELF      a match with ring index 0 (names the slot the token itself has just written, lz.cpp:388-399: the copy's
+ *                    source is the destination, i.e. bytes no one has written): ZO_E_LZ
+ *   ZO_DEV_OVERREAD  (no rejection) the bit reader consumed bits behind the payload's end: zeros here, stale obuf bytes in
+ *                    the reference (:369-374) -- the symbols decoded from there on may differ
+ * Everything else -- bad flags, sizes over the limits, codes without a symbol in either alphabet, over-subscribed length sets
+ * (last symbol in table order wins, with the 10-bit fast table of :361, 376-379 in front of the 15-bit one), indices >= 4096,
+ * lengths that miss encpos -- is the reference's own behaviour and is restated exactly. */
+int zo_decode_ex(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, uint32_t* flags_out) {
     tables_init();
     zo_dbucket* bk = (zo_dbucket*)malloc(sizeof(zo_dbucket) * 256);
     uint8_t (*mtf)[256] = (uint8_t(*)[256])malloc(256 * 256);
@@ -476,26 +515,30 @@ int zo_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out
     uint8_t* blk = (uint8_t*)malloc(ZO_BLOCK_IN + ZO_SENTINEL + 512);
     uint8_t* pay = (uint8_t*)calloc(1, ZO_PAYLOAD_MAX + ZO_SENTINEL + 16);
     uint16_t* lut1 = (uint16_t*)malloc(sizeof(uint16_t) << ZO_MAXLEN1);
+    uint16_t lut1f[1 << ZO_MAXLEN1_FAST];
     int rc = ZO_E_OK;
+    uint32_t flags = 0;
     size_t ip = 0, op = 0;
     if (!bk || !mtf || !tb || !blk || !pay || !lut1) { rc = ZO_E_CAP; goto done; }
     for (int c = 0; c < 256; c++) memcpy(mtf[c], zo_mtfinit, 256);     /* src/libzling_lz.cpp:119-121 */
 
     while (ip < n) {                                                    /* one output block */
         int decpos = 0;
+        if (!block_is_complete(in, n, ip)) { flags |= ZO_DEV_TRUNC; rc = ZO_E_TRUNC; goto done; }
         for (int c = 0; c < 256; c++) { memset(bk[c].offset, 0, sizeof bk[c].offset); bk[c].head = 0; }
         while (ip < n) {
             int flag = in[ip++];
             if (flag != 0 && flag != 1) { rc = ZO_E_FLAG; goto done; }  /* :315-317 */
             if (flag == 0) break;
-            if (ip + 12 > n) { rc = ZO_E_TRUNC; goto done; }
             uint32_t encpos = (uint32_t)in[ip] << 24 | in[ip + 1] << 16 | in[ip + 2] << 8 | in[ip + 3];
             uint32_t rlen = (uint32_t)in[ip + 4] << 24 | in[ip + 5] << 16 | in[ip + 6] << 8 | in[ip + 7];
             uint32_t olen = (uint32_t)in[ip + 8] << 24 | in[ip + 9] << 16 | in[ip + 10] << 8 | in[ip + 11];
             ip += 12;
-            if (rlen > ZO_SUBBLOCK_SYMS || olen > ZO_PAYLOAD_MAX) { rc = ZO_E_BLOCKSIZE; goto done; }  /* :326-328 */
-            if (ip + olen > n || olen < 273) { rc = ZO_E_TRUNC; goto done; }
-            if (encpos > ZO_BLOCK_IN) { rc = ZO_E_LZ; goto done; }
+            if (rlen > ZO_SUBBLOCK_SYMS || olen > ZO_PAYLOAD_MAX) {     /* :326-328 */
+                if ((rlen | olen) & 0x80000000u) flags |= ZO_DEV_SIGNED;
+                rc = ZO_E_BLOCKSIZE; goto done;
+            }
+            if (olen < ZO_TABLE_BYTES) { flags |= ZO_DEV_SHORT; rc = ZO_E_LZ; goto done; }
             memcpy(pay, in + ip, olen);
             memset(pay + olen, 0, 16);
             ip += olen;
@@ -507,18 +550,20 @@ int zo_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out
             for (int i = 0; i < ZO_NSYM2; i += 2) { l2[i] = pay[pp] / 16; l2[i + 1] = pay[pp] % 16; pp++; }
             zo_make_encode_table(l1, c1, ZO_NSYM1, ZO_MAXLEN1);
             zo_make_encode_table(l2, c2, ZO_NSYM2, ZO_MAXLEN2);
-            make_decode_table(l1, c1, lut1, ZO_NSYM1, ZO_MAXLEN1);
+            make_decode_table(l1, c1, lut1, ZO_NSYM1, ZO_MAXLEN1);      /* :358-365: two levels for alphabet 1 */
+            make_decode_table(l1, c1, lut1f, ZO_NSYM1, ZO_MAXLEN1_FAST);
             make_decode_table(l2, c2, lut2, ZO_NSYM2, ZO_MAXLEN2);
 
-            uint64_t acc = 0;
+            uint64_t acc = 0, loaded = 0;
             int nb = 0;
             for (uint32_t i = 0; i < rlen; i++) {                       /* :368-402 */
                 if (nb < 32) {
                     uint32_t w = 0;
                     for (int k = 0; k < 4; k++) w |= (uint32_t)(pp < olen ? pay[pp] : 0) << (8 * k), pp++;
-                    acc |= (uint64_t)w << nb; nb += 32;
+                    acc |= (uint64_t)w << nb; nb += 32; loaded += 32;
                 }
-                uint32_t sym = lut1[acc & 0x7FFF];
+                uint32_t sym = lut1f[acc & ((1u << ZO_MAXLEN1_FAST) - 1)];     /* :376-379 */
+                if (sym == 0xFFFF) sym = lut1[acc & 0x7FFF];
                 if (sym >= ZO_NSYM1) { rc = ZO_E_CODE1; goto done; }
                 acc >>= l1[sym]; nb -= (int)l1[sym];
                 tb[i] = (uint16_t)sym;
@@ -529,21 +574,27 @@ int zo_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out
                     uint32_t bits = (uint32_t)(acc & ((1u << g_idx_blen[c]) - 1));
                     acc >>= g_idx_blen[c]; nb -= g_idx_blen[c];
                     uint32_t idx = g_idx_base[c] + bits;
-                    if (idx >= ZO_RING || i + 1 >= rlen) { rc = ZO_E_EXBITS; goto done; }
-                    tb[++i] = (uint16_t)idx;
+                    if (idx >= ZO_RING) { rc = ZO_E_EXBITS; goto done; }      /* :396-399 (the largest index the 32 codes can name is
+                                                                                 * 3840 + 255: the reference's test never fires either) */
+                    tb[++i] = (uint16_t)idx;                                  /* may be entry `rlen` itself: the reference stores it behind
+                                                                                 * the counted entries too, and its replay reads it there */
                 }
             }
+            if (loaded - (uint64_t)nb > 8ull * (olen - ZO_TABLE_BYTES)) flags |= ZO_DEV_OVERREAD;
+            if (encpos > ZO_BLOCK_IN) { flags |= ZO_DEV_ENCPOS; rc = ZO_E_LZ; goto done; }
 
             /* ZlingRolzDecoder::Decode, src/libzling_lz.cpp:318-376 */
             uint16_t mru[256][2];
             memset(mru, 0, sizeof mru);
             int opos = decpos;
             uint32_t ti = 0;
-            if (opos == 0 && ti < rlen) blk[opos++] = (uint8_t)tb[ti++];
-            if (opos == 1 && ti < rlen) blk[opos++] = (uint8_t)tb[ti++];
+            while (opos < 2 && ti < rlen) {                              /* :327-328: the block's two opening entries, raw */
+                if (tb[ti] >= 258) { flags |= ZO_DEV_OPENING; rc = ZO_E_LZ; goto done; }
+                blk[opos++] = (uint8_t)tb[ti++];
+            }
             while (ti < rlen) {
                 uint32_t v = tb[ti];
-                if (opos < 2 || opos + ZO_MATCH_MAX + 4 > ZO_BLOCK_IN + ZO_SENTINEL) { rc = ZO_E_LZ; goto done; }
+                if (opos + ZO_MATCH_MAX + 4 > ZO_BLOCK_IN + ZO_SENTINEL) { rc = ZO_E_LZ; goto done; }   /* (opos <= encpos <= 16 MiB: never) */
                 zo_dbucket* b = &bk[blk[opos - 1]];
                 b->head = (uint16_t)((b->head + 1) & (ZO_RING - 1));   /* GetMatchAndUpdate :388-399 */
                 b->offset[b->head] = (uint32_t)opos;
@@ -566,6 +617,7 @@ int zo_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out
                     int mlen = (int)v - 258 + ZO_MATCH_MIN;
                     uint32_t idx = tb[ti + 1];
                     ti += 2;
+                    if (idx == 0) { flags |= ZO_DEV_SELF; rc = ZO_E_LZ; goto done; }
                     uint32_t src = b->offset[(b->head - idx) & (ZO_RING - 1)];
                     for (int k = 0; k < mlen; k++) blk[opos + k] = blk[src + k];   /* :91-104 forward copy */
                     opos += mlen;
@@ -584,5 +636,10 @@ int zo_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out
 done:
     free(bk); free(mtf); free(tb); free(blk); free(pay); free(lut1);
     *out_len = op;
+    if (flags_out) *flags_out = flags;
     return rc;
+}
+
+int zo_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len) {
+    return zo_decode_ex(in, n, out, cap, out_len, NULL);
 }

@@ -170,8 +170,9 @@ def book_match(X):
         s_or_b32 s56, s56, s58
         s_waitcnt lgkmcnt(0)
         v_and_b32 v36, 0xffff, v40
-        v_lshl_or_b32 v43, v40, 16, s56
         v_cmp_ne_u32 vcc, s56, v36
+        v_lshl_or_b32 v43, v40, 16, s56
+        s_nop 0
         v_cndmask_b32 v40, v40, v43, vcc
         ds_write_b32 v39, v40
     """)

@@ -78,7 +78,10 @@ def corrupt_cases(oracle):
     [(name, bytes, oracle error code)].  Built from the one-sub-block stream of text_64k:
       * code1  -- all 257 nibble bytes of length table 1 zeroed: no code exists, the first 15-bit lookup misses;
       * code2  -- the 16 nibble bytes of length table 2 zeroed: the first match's index code misses;
-      * exbits -- rlen cut so that the last u16 entry is a match symbol whose index entry falls outside the sub-block."""
+      * lz     -- rlen cut so that the last counted u16 entry is a match symbol: the reference keeps the index entry behind it (it is
+                  stored at tbuf[rlen], src/libzling.cpp:398, and the replay reads it there), so the sub-block decodes short of its
+                  encpos: "lzdecode failed".  (The third check, "bad ex-bits", :399, cannot fire at all: the 32 index codes name at
+                  most 3840 + 255.  tests/test_oracle_hostile.py holds this against the real reference.)"""
     x = get("text_64k")
     z = oracle.encode(x, 0)
     pay = 13                                           # flag + encpos + rlen + olen
@@ -89,4 +92,4 @@ def corrupt_cases(oracle):
     assert (tok[first_match] & 0xFFFF) >= 258 and not ((tok[:first_match] & 0xFFFF) >= 258).any()
     ex = z.copy()
     ex[5:9] = list(int(first_match + 1).to_bytes(4, "big"))       # u16 index of the first match == its token index
-    return x, [("code1", c1, -4), ("code2", c2, -5), ("exbits", ex, -6)]
+    return x, [("code1", c1, -4), ("code2", c2, -5), ("lz", ex, -7)]

@@ -84,7 +84,7 @@ def test_corrupt_streams_map_to_reference_errors(zl, oracle):
 
 def test_each_huffman_validity_check_deterministically(zl, oracle):
     x, cases = corpus.corrupt_cases(oracle)
-    want_gpu = {"code1": -12, "code2": -13, "exbits": -14}
+    want_gpu = {"code1": -12, "code2": -13, "lz": -15}
     for name, bad, ocode in cases:
         assert oracle.decode(bad, x.size)[0] == ocode, name
         with pytest.raises(zl.ZlngError) as e:

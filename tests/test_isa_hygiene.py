@@ -44,3 +44,80 @@ def test_chain_tile_restores_exec(tmp_path):
         body = lines[a + 1: b]
         assert not any(ln.startswith("s_endpgm") or ln.startswith("s_setpc_b64 s[30:31]") for ln in body)
         assert not any("s_mov_b64 exec" in ln for ln in body)
+
+
+# ---- gfx940 / gfx950: a VALU that writes an SGPR or VCC and a VALU that reads it need two wait states between them ----------------
+# (LLVM GCNHazardRecognizer, checkVALUHazards under hasVDecCoExecHazard: VALUWriteSGPRVALUReadWaitstates = 2; hipcc pads its own
+# code -- `v_cmp; s_nop 0 + one more instruction; v_cndmask` on gfx950, nothing on gfx90a -- but never looks inside an asm statement.)
+_SREG = re.compile(r"\b(vcc(?:_lo|_hi)?\b|s\[(\d+):(\d+)\]|s(\d+)\b)")
+
+
+def _sregs(text):
+    """Scalar registers named in an operand string, as a set of ints (vcc = {1000, 1001})."""
+    out = set()
+    for m in _SREG.finditer(text):
+        if m.group(1).startswith("vcc"):
+            out |= {1000} if m.group(1) == "vcc_lo" else ({1001} if m.group(1) == "vcc_hi" else {1000, 1001})
+        elif m.group(2) is not None:
+            out |= set(range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add(int(m.group(4)))
+    return out
+
+
+def valu_sgpr_hazards(lines, need=2):
+    """[(line number, writer, reader)] of VALU-writes-SGPR -> VALU-reads pairs fewer than `need` wait states apart, scanning the
+    assembly in text order (a taken branch only lengthens the distance)."""
+    recent = []                                       # [(registers written, wait states since, text, line)]
+    bad = []
+    for ln, text in enumerate(lines):
+        if not text or text.endswith(":") or text.startswith(".") or text.startswith(";"):
+            continue
+        parts = text.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+        if not re.match(r"^[svdgb]_|^global_|^buffer_|^ds_|^flat_|^scratch_", op):
+            continue
+        ops = [a.strip() for a in args.split(",")]
+        if op.startswith("v_"):
+            carry = "_co_" in op or op.startswith("v_div_scale")
+            ndst = 2 if carry else 1
+            reads = _sregs(", ".join(ops[ndst:]))
+            if op.startswith("v_div_fmas"):
+                reads |= {1000, 1001}
+            for regs, dist, wtext, wln in recent:
+                if dist < need and regs & reads:
+                    bad.append((ln, wtext, text))
+            writes = _sregs(", ".join(ops[:ndst]))
+            for r in recent:
+                r[1] += 1
+            if writes:
+                recent.append([writes, 0, text, ln])
+        else:
+            step = 1
+            m = re.match(r"s_nop\s+(\d+)", text)
+            if m:
+                step = int(m.group(1)) + 1
+            for r in recent:
+                r[1] += step
+        recent = [r for r in recent if r[1] < need]
+    return bad
+
+
+def test_the_hazard_scanner_sees_what_it_should():
+    assert valu_sgpr_hazards(["v_cmp_ne_u32_e32 vcc, v1, v2", "v_cndmask_b32_e32 v0, v1, v2, vcc"])
+    assert valu_sgpr_hazards(["v_cmp_ne_u32_sdwa vcc, v1, v2 src0_sel:BYTE_0 src1_sel:DWORD", "s_cbranch_scc0 .L1",
+                              "v_cndmask_b32_dpp v0, v0, v0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf"])      # round 4's step: one state
+    assert not valu_sgpr_hazards(["v_cmp_ne_u32_sdwa vcc, v1, v2 src0_sel:BYTE_0 src1_sel:DWORD", "s_cbranch_scc0 .L1", "s_nop 0",
+                                  "v_cndmask_b32_dpp v0, v0, v0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf"])
+    assert valu_sgpr_hazards(["v_readlane_b32 s5, v1, 3", "v_mov_b32_e32 v2, s5"])
+    assert not valu_sgpr_hazards(["v_readlane_b32 s5, v1, 3", "s_nop 1", "v_mov_b32_e32 v2, s5"])
+    assert valu_sgpr_hazards(["v_cmp_eq_u32_e64 s[4:5], v1, v2", "s_mov_b32 s9, 0", "v_cndmask_b32_e64 v0, v1, v2, s[4:5]"])
+    assert not valu_sgpr_hazards(["v_cmp_eq_u32_e64 s[4:5], v1, v2", "v_cndmask_b32_e64 v0, v1, v2, s[6:7]"])
+    assert not valu_sgpr_hazards(["s_ashr_i64 vcc, vcc, 1", "v_cndmask_b32_e32 v0, v1, v2, vcc"])               # a scalar writer owes nothing
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("name", ["mtf_rank", "decode", "rolz_wg", "rolz_parse", "huffman"])
+def test_no_valu_reads_an_sgpr_a_valu_wrote_less_than_two_wait_states_ago(tmp_path, name):
+    bad = valu_sgpr_hazards(isa_of(tmp_path, name))
+    assert not bad, (len(bad), bad[:8])

@@ -1,0 +1,92 @@
+"""The oracle's verdicts on hostile streams against the REAL reference (oracle/_ref), on the CPU.
+
+The GPU differential (tests/test_gpu_hostile.py) compares the HIP decoder with the oracle; this test is what entitles the oracle
+to that role: for every mutant on which none of the oracle's own rules fired (flags == 0, zlng_oracle.h ZO_DEV_*) the reference --
+run in a forked child, because on hostile input it may read or write memory it does not own -- must reach the same verdict (the
+same exception message class, src/libzling.cpp:316, 327, 382, 392, 399, 407, or success) and must have written the same bytes
+(on success all of them; on an error the complete blocks in front of it).  Where a rule did fire the reference's behaviour is
+only counted: those are the documented deviations."""
+import collections
+import hashlib
+import os
+import pickle
+import signal
+
+import numpy as np
+import pytest
+
+import hostile
+from oracle_py import Reference
+
+MSG = {"invalid encflag.": -2, "invalid block size.": -3, "(bad code1)": -4, "(bad code2)": -5, "(bad ex-bits)": -6, "lzdecode failed.": -7}
+
+
+def ref_verdict(ref, m, cap, timeout=3):
+    """(class, bytes written, sha256 of them) from the reference in a forked child; ("crash", signal) if it dies."""
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            import faulthandler
+            faulthandler.disable()                                      # a reference that dies here is a result, not a report
+            os.close(r)
+            signal.alarm(timeout)
+            rc, y, msg = ref.decode(m, cap)
+            cls = 0 if rc == 0 else (-1 if rc == -1 else next((v for k, v in MSG.items() if msg.endswith(k)), -99))
+            os.write(w, pickle.dumps((cls, int(y.size), hashlib.sha256(y.tobytes()).hexdigest())))
+        finally:
+            os._exit(0)
+    os.close(w)
+    data = b""
+    while True:
+        chunk = os.read(r, 65536)
+        if not chunk:
+            break
+        data += chunk
+    os.close(r)
+    _, status = os.waitpid(pid, 0)
+    if not data:
+        return ("crash", os.WTERMSIG(status) if os.WIFSIGNALED(status) else -1, None)
+    return pickle.loads(data)
+
+
+@pytest.mark.skipif(not Reference.available(), reason="oracle/_ref not built (no /root/reference here)")
+def test_oracle_verdicts_are_the_references_wherever_the_reference_is_defined(oracle):
+    ref = Reference()
+    stats = collections.Counter()
+    deviations = collections.Counter()
+    bad = []
+    for name, m, cap in hostile.mutants(oracle, 20260929, 1600):
+        rc, y, flags = oracle.decode_ex(m, cap)
+        stats[(name.split(":")[0], rc)] += 1
+        if flags & 32:                                                  # ZO_DEV_SELF: the reference's copy loop never ends on a source
+            deviations[(flags, "reference: hangs")] += 1                 # that is its destination (src/libzling_lz.cpp:91-95)
+            continue
+        got = ref_verdict(ref, m, cap)
+        if flags:
+            deviations[(flags, "same verdict" if got[0] == rc else "reference: %s" % (got[0],))] += 1
+            continue
+        mine = (rc, int(y.size), hashlib.sha256(y.tobytes()).hexdigest())
+        if tuple(got) != mine:
+            bad.append((name, mine[:2], tuple(got)[:2]))
+    assert not bad, bad[:10]
+    # every verdict class of the decoder was reached without a deviation rule, i.e. was held against the reference
+    assert {rc for (_, rc) in stats} >= {0, -2, -3, -4, -5, -7, -8}      # (-6, the ex-bits test, cannot fire: the codes name at most index 4095)
+    print(sorted(deviations.items()))
+
+
+@pytest.mark.skipif(not Reference.available(), reason="oracle/_ref not built (no /root/reference here)")
+def test_over_subscribed_tables_decode_like_the_reference_two_level_lookup(oracle):
+    """An over-subscribed length set makes table entries collide: the reference fills in symbol order (the last symbol wins,
+    src/libzling_huffman.cpp:140-153) and asks its 10-bit fast table first (src/libzling.cpp:361, 376-379), so a short code beats a
+    longer one of a later symbol.  Mutants that ONLY touch table bytes, many of them, success or not."""
+    ref = Reference()
+    n_ok = 0
+    for name, m, cap in hostile.mutants(oracle, 77, 900, classes=("table",)):
+        rc, y, flags = oracle.decode_ex(m, cap)
+        if flags:
+            continue
+        got = ref_verdict(ref, m, cap)
+        assert tuple(got) == (rc, int(y.size), hashlib.sha256(y.tobytes()).hexdigest()), name
+        n_ok += rc == 0
+    assert n_ok >= 20                                                   # damaged tables that still decode: the interesting half
