@@ -137,6 +137,12 @@ def expected_ranges(args, world, single, source, ranges, live_max_bytes):
             key = pins["weak"].get(str(world))
         if key and [(r["offset"], r["bytes"]) for r in key["ranks"]] == [tuple(r) for r in ranges]:
             return [(r["zlng_bytes"], r["sha256"]) for r in key["ranks"]], "pins (tests/golden/manifest.json sharded_ranges: the real reference over the whole %d-byte stream)" % total
+    try:                                                             # BASELINE config 4's per-GPU share (8 GiB at e4), pinned from a full reference run
+        c4 = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json"))).get("config4_share")
+    except Exception:
+        c4 = None
+    if c4 and world == 1 and source == "synthetic" and args.level == c4["level"] and args.size == c4["bytes"]:
+        return [(c4["zlng_bytes"], c4["sha256"])], "pins (tests/golden/manifest.json config4_share: the real reference over the whole %d-byte stream at e%d)" % (total, args.level)
     if args.no_cpu_baseline:
         return None, "--no-cpu-baseline"
     if total > live_max_bytes:
