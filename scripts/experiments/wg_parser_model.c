@@ -49,15 +49,35 @@ typedef struct {
     int link_lane;                    /* in-window predecessor in the hash slot (fix), -1 = snapshot node0 */
     int ty2, tlen2, mlen2, mnode2, link2, hard, hardcls;
     int has_ev, cond, eff; uint32_t s0b;
+    int slot;                         /* ring slot the committed token got (ghosts) */
 } lane_t;
+#define LNONE (-(1 << 20))             /* link_lane: no in-round predecessor (lane indices run from -ng: ghosts are negative) */
+#define LANE_REF(a) (-1 - ((a) + MAXG)) /* match source / chain link that is a lane of the round (or a ghost), as a negative "slot" */
+#define REF_LANE(m) (-1 - (m) - MAXG)
 
 static struct {
     long rounds, tokens, iters, hard[8], serial, committed, cut_rounds, fixes, lfixes, maxit;
     long hist_it[16];
     long prefix_rounds;
+    long windows, sync_rounds, first_rounds, ghost_sum, ghost_max, ghost_over, ghost_a1, spec_lanes, lanes_sum;
 } st;
 
 static int precise_risk = 1, only_s = 0, max_tok = 1 << 30, guess_mru = 0;
+/* Round 5: the PIPELINED form, modelled before anything is built.  grid = 1: windows lie on a fixed grid of NL
+ * positions (a round takes the grid window that holds the next token start, from that start on), so that the NEXT window's
+ * positions are known while this one is being resolved.  stale = 1: phase 1 of window w + 1 is evaluated against the dictionary as
+ * it is BEFORE the first commit of window w (what a second set of wavefronts would do beside the iterate phase of window w), and
+ * every token committed since -- the rest of window w, serial replays included -- is a GHOST: a member of S in front of lane 0 that
+ * is final, is never re-evaluated and takes part in nothing but the dictionary relations (same hash slot, ring slots handed out in
+ * its bucket, lazy-probe keys).  More than ghost_cap ghosts (a two-word rank mask holds 128), or a window that was not the one
+ * speculated (a long match jumped over it), falls back to a synchronous phase 1 ("sync round").  Exactness is checked like before:
+ * every token against the oracle's, and the commit's head / link formulas against the dictionary. */
+static int grid = 0, stale = 0, ghost_cap = 128;
+/* grid = 2: FLOATING windows (a round starts at the next token start, as the kernel's do) with stale = 1: while a round is resolved the
+ * positions [P + ahead_c, P + ahead_c + ahead_r) are evaluated ahead; the next round uses them where it lies inside that range and is
+ * cut short where the range ends; it is a sync round when it starts in front of the range. */
+static int ahead_c = 176, ahead_r = 336;
+#define MAXG 512
 static int prefix_pct = 0;   /* > 0: after the FIRST iteration, if the first changed token has at least prefix_pct % of the round's tokens in front of it,
                                 commit that prefix and start the next round at the changed token instead of iterating (round 4 experiment) */
 static int ring_dist(int node, int head0) { return (node - head0 - 1) & (ZO_RING - 1); }
@@ -164,14 +184,40 @@ static uint32_t serial_token(zo_stream* s, const uint8_t* ibuf, int ilen, int* i
     return word;
 }
 
+/* lane <-> position: everything that depends on the text only, then phase 1 against the dictionary as it is now */
+static void setup_lane(const zo_stream* s, const uint8_t* ibuf, int ilen, int pos, int depth, int lazy1, int lazy2, int NL, lane_t* l) {
+    memset(l, 0, sizeof *l);
+    l->pos = pos; l->live = 1; l->canm = pos + ZO_SENTINEL < ilen;
+    l->ctx = ibuf[pos - 1];
+    uint32_t w4 = 0; { uint8_t t[4] = {0, 0, 0, 0}; for (int k = 0; k < 4 && pos + k < ilen + 0; k++) t[k] = ibuf[pos + k]; memcpy(&w4, t, 4); }
+    uint32_t h = w4 + ((w4 >> 16) & 0xFF) * 137u + (w4 >> 24) * 13337u;
+    l->hc = h % ZO_HASH; l->chk = (h / ZO_HASH) % 256; l->key = l->ctx << 13 | l->hc;
+    l->b0 = w4 & 0xFF;
+    l->cw = (w4 & 0xFF) << 8 | ((w4 >> 8) & 0xFF);
+    l->ek = pos >= 3 ? ibuf[pos - 3] : 0;
+    l->ew = (uint32_t)(pos >= 2 ? ibuf[pos - 2] : 0) << 8 | ibuf[pos - 1];
+    if (l->canm) speculate(s, ibuf, pos, depth, lazy1, lazy2, NL, l);
+    else { l->sp_match = 0; l->sp_len = 3; l->dmin = ZO_RING - 1; }
+}
+
 /* NOTE on MRU bookkeeping: the model keeps `mru` in the reference's convention (pushes applied right after a token).
  * The window algorithm attaches the push to the NEXT token start ("boundary event"); the state the window sees at its
  * start, mru0, is the reference state with the push that follows the last token still pending, described by prevty. */
 
 static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int level, int NL, int fix, uint32_t* tok_out, int* cuts, int* ncut) {
     const int depth = k_level_cfg[level][0], lazy1 = k_level_cfg[level][1], lazy2 = k_level_cfg[level][2];
-    static lane_t L[MAXNL];
-    static uint8_t S[MAXNL + 300];
+    static lane_t Lbuf[MAXG + MAXNL];
+    static uint8_t Sbuf[MAXG + MAXNL + 300];
+    lane_t* const L = Lbuf + MAXG;                 /* L[-1] is the newest ghost, L[-ng] the oldest */
+    uint8_t* const S = Sbuf + MAXG;
+    static lane_t SP[MAXNL], SPcur[MAXNL];         /* stale mode: phase 1 of the next grid window; of the current one (its follow-up rounds) */
+    long cur_log = 0; int cur_valid = 0, sp_pos = 0;
+    static lane_t* clog = NULL;                    /* every committed token of the block, in order (ghost source) */
+    if (!clog) clog = (lane_t*)malloc(sizeof(lane_t) * (ZO_BLOCK_IN + 64));
+    long nlog = 0, sp_log = 0;                     /* sp_log: length of the log when SP was taken */
+    int sp_win = -1, sp_n = 0, cur_win = -1, ng = 0;
+    static int slot_buf[MAXG + MAXNL];
+    int* const slot_of = slot_buf + MAXG;
     int q = 0, nt = 0, nsub = 0;
     zo_reset_buckets(s);
     while (q < ilen) {
@@ -195,7 +241,14 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                  * simpler: let it push, and mark prevty = NONE-equivalent "already applied" */
                 int ty;
                 uint16_t before[256][2]; memcpy(before, mru, sizeof mru);
+                const int spos = q;
                 tok_out[nt++] = serial_token(s, ibuf, ilen, &q, &opos, mru, depth, lazy1, lazy2, &ty);
+                if (stale) {                                   /* a replayed token wrote the dictionary as well: a ghost for whatever was speculated before */
+                    lane_t* l = &clog[nlog];
+                    setup_lane(s, ibuf, ilen, spos, 0, 0, 0, NL, l);      /* depth 0: text-derived fields only (the walk visits nothing) */
+                    l->has_ev = 0; l->slot = s->bucket[ibuf[spos - 1]].head;
+                    nlog++;
+                }
                 /* back to the window convention: state before the push of this token; W1's own swap (m[1]=m[0]; m[0]=w) IS
                  * that push with key ibuf[q-3] -- in both conventions the event is "after W1: unconditional push" */
                 memcpy(mru, before, sizeof mru);
@@ -204,29 +257,58 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 continue;
             }
             const int P = q;
-            const int nlive = ilen - P < NL ? ilen - P : NL;
-            /* ---- lane setup + phase 1 */
+            /* grid = 1: the round takes the grid window that holds q, from q on (the block's text starts at position 2) */
+            const int win = grid == 1 ? (P - 2) / NL : -1;
+            int wend = grid == 1 ? (2 + (win + 1) * NL < ilen ? 2 + (win + 1) * NL : ilen) : (ilen - P < NL ? ilen : P + NL);
+            const int first_round = grid == 1 ? win != cur_win : 1;
+            if (grid == 1 && first_round) { st.windows++; st.first_rounds++; cur_valid = 0; }
+            /* ---- lane setup + phase 1: now, or (stale) what was evaluated while the window before this one was being resolved */
+            ng = 0;
+            int use_sp = 0;
+            const lane_t* src = NULL; int src_base = 0; long src_log = 0;
+            if (stale && grid == 1) {
+                if (first_round && sp_win == win) { memcpy(SPcur, SP, sizeof(lane_t) * (size_t)sp_n); cur_log = sp_log; cur_valid = 1; }
+                if (cur_valid) { src = SPcur; src_base = 2 + win * NL; src_log = cur_log; use_sp = 1; }
+            } else if (stale && grid == 2 && sp_n > 0 && P >= sp_pos && P < sp_pos + sp_n) {
+                src = SP; src_base = sp_pos; src_log = sp_log; use_sp = 1;
+                if (wend > sp_pos + sp_n) wend = sp_pos + sp_n;            /* the range evaluated ahead ends here */
+            }
+            if (use_sp && (nlog - src_log > ghost_cap || nlog - src_log > MAXG)) { use_sp = 0; st.ghost_over++; if (grid == 2) wend = ilen - P < NL ? ilen : P + NL; }
+            const int nlive = wend - P;
+            cur_win = win;
+            if (use_sp) {
+                ng = (int)(nlog - src_log);
+                for (int i = 0; i < ng; i++) { L[-1 - i] = clog[nlog - 1 - i]; S[-1 - i] = 1; slot_of[-1 - i] = L[-1 - i].slot; }
+                for (int g = 0; g < nlive; g++) L[g] = src[P + g - src_base];
+                st.ghost_sum += ng; if (ng > st.ghost_max) st.ghost_max = ng;
+            } else {
+                for (int g = 0; g < nlive; g++) setup_lane(s, ibuf, ilen, P + g, depth, lazy1, lazy2, NL, &L[g]);
+                if (grid) st.sync_rounds++;
+            }
+            st.lanes_sum += nlive;
             for (int g = 0; g < nlive; g++) {
                 lane_t* l = &L[g];
-                memset(l, 0, sizeof *l);
-                const int pos = P + g;
-                l->pos = pos; l->live = 1; l->canm = pos + ZO_SENTINEL < ilen;
-                l->ctx = ibuf[pos - 1];
-                uint32_t w4 = 0; { uint8_t t[4] = {0, 0, 0, 0}; for (int k = 0; k < 4 && pos + k < ilen + 0; k++) t[k] = ibuf[pos + k]; memcpy(&w4, t, 4); }
-                uint32_t h = w4 + ((w4 >> 16) & 0xFF) * 137u + (w4 >> 24) * 13337u;
-                l->hc = h % ZO_HASH; l->chk = (h / ZO_HASH) % 256; l->key = l->ctx << 13 | l->hc;
-                l->b0 = w4 & 0xFF;
-                l->cw = (w4 & 0xFF) << 8 | ((w4 >> 8) & 0xFF);
-                l->ek = pos >= 3 ? ibuf[pos - 3] : 0;
-                l->ew = (uint32_t)(pos >= 2 ? ibuf[pos - 2] : 0) << 8 | ibuf[pos - 1];
-                if (l->canm) speculate(s, ibuf, pos, depth, lazy1, lazy2, NL, l);
-                else { l->sp_match = 0; l->sp_len = 3; l->dmin = ZO_RING - 1; }
                 l->ty = l->sp_match ? TY_MATCH : TY_LIT;
                 l->mlen = l->sp_len; l->tlen = l->sp_match ? l->sp_len : 1;
-                if (guess_mru && !l->sp_match && pos + 1 < ilen) {       /* first guess from the MRU slots at the start of the round */
+                if (guess_mru && !l->sp_match && l->pos + 1 < ilen) {       /* first guess from the MRU slots at the start of the round */
                     if (mru[l->ctx][0] == l->cw) { l->ty = TY_W0; l->tlen = 2; } else if (mru[l->ctx][1] == l->cw) { l->ty = TY_W1; l->tlen = 2; }
                 }
-                l->mnode_slot = l->sp_node; l->link_lane = -1;
+                l->mnode_slot = l->sp_node; l->link_lane = LNONE;
+            }
+            /* stale: the next grid window is evaluated NOW -- beside this window's first iterate phase, i.e. before anything of this
+             * window is committed -- and everything committed from here on is a ghost for it */
+            if (stale && grid == 1 && first_round && wend < ilen) {
+                sp_n = wend + NL < ilen ? NL : ilen - wend;
+                for (int g = 0; g < sp_n; g++) setup_lane(s, ibuf, ilen, wend + g, depth, lazy1, lazy2, NL, &SP[g]);
+                sp_win = win + 1; sp_log = nlog; st.spec_lanes += sp_n;
+            }
+            if (stale && grid == 2) {                              /* floating: a fixed range ahead of this round's start */
+                sp_pos = P + ahead_c; sp_n = 0;
+                if (sp_pos < ilen) {
+                    sp_n = sp_pos + ahead_r < ilen ? ahead_r : ilen - sp_pos;
+                    for (int g = 0; g < sp_n; g++) setup_lane(s, ibuf, ilen, sp_pos + g, depth, lazy1, lazy2, NL, &SP[g]);
+                    sp_log = nlog; st.spec_lanes += sp_n;
+                }
             }
             /* ---- iterate to the fixed point */
             int limit = nlive, limit_is_hard = 0, it = 0, tok_limit = nlive;
@@ -253,62 +335,63 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 /* E step C: match validity / exact in-window evaluation, MRU check, new type */
                 for (int g = 0; g < nlive; g++) {
                     lane_t* l = &L[g];
-                    int k = 0, a1 = -1, a2 = -1;
-                    for (int j = g - 1; j >= 0; j--) if (S[j] && L[j].canm) {
+                    int k = 0, a1 = LNONE, a2 = LNONE;
+                    for (int j = g - 1; j >= -ng; j--) if (S[j] && L[j].canm) {
                         if (L[j].ctx == l->ctx) k++;
-                        if (L[j].key == l->key) { if (a1 < 0) a1 = j; else if (a2 < 0) a2 = j; }
+                        if (L[j].key == l->key) { if (a1 == LNONE) a1 = j; else if (a2 == LNONE) a2 = j; }
                     }
                     l->hard = 0; l->hardcls = 0;
                     if (only_s && !S[g]) { l->ty2 = l->ty; l->tlen2 = l->tlen; l->mlen2 = l->mlen; l->mnode2 = l->mnode_slot; l->link2 = l->link_lane; continue; }
-                    int is_match = 0, mlen = 3, mnode = 0, link = -1;
+                    int is_match = 0, mlen = 3, mnode = 0, link = LNONE;
                     if (l->canm) {
                         const int ring = l->dmin <= k;
                         /* lazy read sets: accepted starts <= g (own insert included, src/libzling_lz.cpp:271) */
-                        int lconf[2] = {0, 0}, lhit[2] = {-1, -1}, lhits[2] = {0, 0};
+                        int lconf[2] = {0, 0}, lhit[2] = {LNONE, LNONE}, lhits[2] = {0, 0};
                         for (int j2 = 0; j2 < 2; j2++) if (l->lwant[j2]) {
                             int cnt = 0;
-                            for (int j = g; j >= 0; j--) if (S[j] || j == g) if (L[j].canm) {
-                                if (L[j].key == l->lkey[j2]) { if (lhit[j2] < 0) lhit[j2] = j; lhits[j2]++; }
+                            for (int j = g; j >= -ng; j--) if (S[j] || j == g) if (L[j].canm) {
+                                if (L[j].key == l->lkey[j2]) { if (lhit[j2] == LNONE) lhit[j2] = j; lhits[j2]++; }
                                 if ((int)L[j].ctx == l->lctx[j2]) cnt++;
                             }
                             lconf[j2] = precise_risk ? cnt > l->ld[j2] : (l->lrisk[j2] && cnt > 0);   /* a visited ring slot at distance d is rewritten by the (d+1)-th insert */
                         }
                         const int ring0 = l->has0 && l->d0 <= k, ring1 = l->has1 && l->d1 <= k;
                         const int lvl0fix = fix && level == 0;
-                        if (lvl0fix ? (a1 >= 0 ? (a2 < 0 && ring0) : ring0) : ring) { l->hard = 1; l->hardcls = 2; }
-                        else if (lvl0fix && a1 < 0 && ring1) {
+                        if (lvl0fix ? (a1 > LNONE ? (a2 == LNONE && ring0) : ring0) : ring) { l->hard = 1; l->hardcls = 2; }
+                        else if (lvl0fix && a1 == LNONE && ring1) {
                             /* node 1's slot was rewritten by a start of this round: it now holds a later position than node 0's,
                              * so the reference's chain-end test (src/libzling_lz.cpp:265) stops the walk after node 0 */
                             mlen = l->len0 > 3 ? l->len0 : 3; mnode = l->node0; is_match = mlen >= ZO_MATCH_MIN; st.fixes++;
                         }
-                        else if (a1 >= 0) {
+                        else if (a1 > LNONE) {
+                            if (a1 < 0) st.ghost_a1++;
                             if (fix && level == 0) {
                                 /* chain = [a1, a2 | node0] (depth 2): exact from the window's text */
                                 const uint8_t* p = ibuf + l->pos;
                                 int l1 = L[a1].chk == l->chk ? common_len(p, ibuf + L[a1].pos) : 0;
                                 int l2, n2;
-                                if (a2 >= 0) { l2 = L[a2].chk == l->chk ? common_len(p, ibuf + L[a2].pos) : 0; n2 = -1 - a2; }
+                                if (a2 > LNONE) { l2 = L[a2].chk == l->chk ? common_len(p, ibuf + L[a2].pos) : 0; n2 = LANE_REF(a2); }
                                 else { l2 = l->has0 ? l->len0 : 0; n2 = l->node0; }
                                 mlen = 3; mnode = 0;
-                                if (l1 > mlen) { mlen = l1; mnode = -1 - a1; }
-                                if (mlen != ZO_MATCH_MAX && (a2 >= 0 || l->has0) && l2 > mlen) { mlen = l2; mnode = n2; }
+                                if (l1 > mlen) { mlen = l1; mnode = LANE_REF(a1); }
+                                if (mlen != ZO_MATCH_MAX && (a2 > LNONE || l->has0) && l2 > mlen) { mlen = l2; mnode = n2; }
                                 link = a1;
                                 is_match = mlen >= ZO_MATCH_MIN;
                                 st.fixes++;
                             } else if (fix && level > 0) {
                                 /* generic depth: chain = [a1, a2] ++ the first depth - j nodes of the snapshot's chain (j <= 2) */
-                                int a3 = -1;
-                                for (int j = a2 - 1; a2 >= 0 && j >= 0; j--) if (S[j] && L[j].canm && L[j].key == l->key) { a3 = j; break; }
-                                if (a3 >= 0 || depth < 3) { l->hard = 1; l->hardcls = 1; }
+                                int a3 = LNONE;
+                                for (int j = a2 - 1; a2 > LNONE && j >= -ng; j--) if (S[j] && L[j].canm && L[j].key == l->key) { a3 = j; break; }
+                                if (a3 > LNONE || depth < 3) { l->hard = 1; l->hardcls = 1; }
                                 else {
                                     const uint8_t* p = ibuf + l->pos;
-                                    const int jn = a2 >= 0 ? 2 : 1;
+                                    const int jn = a2 > LNONE ? 2 : 1;
                                     mlen = 3; mnode = 0;
                                     int l1 = L[a1].chk == l->chk ? common_len(p, ibuf + L[a1].pos) : 0;
-                                    if (l1 > mlen) { mlen = l1; mnode = -1 - a1; }
-                                    if (a2 >= 0 && mlen != ZO_MATCH_MAX) {
+                                    if (l1 > mlen) { mlen = l1; mnode = LANE_REF(a1); }
+                                    if (a2 > LNONE && mlen != ZO_MATCH_MAX) {
                                         int l2 = L[a2].chk == l->chk ? common_len(p, ibuf + L[a2].pos) : 0;
-                                        if (l2 > mlen) { mlen = l2; mnode = -1 - a2; }
+                                        if (l2 > mlen) { mlen = l2; mnode = LANE_REF(a2); }
                                     }
                                     if (mlen != ZO_MATCH_MAX && l->pl[jn] > mlen) { mlen = l->pl[jn]; mnode = l->pn[jn]; }
                                     link = a1;
@@ -321,21 +404,21 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                             /* lazy probes under mlen */
                             int veto = 0, need_hard = 0;
                             for (int j2 = 0; j2 < 2 && !veto; j2++) if (l->lwant[j2]) {
-                                const int conflict = lhit[j2] >= 0 || lconf[j2];
+                                const int conflict = lhit[j2] > LNONE || lconf[j2];
                                 if (!conflict && mlen == l->sp_len) { /* speculative probe stands */
                                     /* per-probe veto is not kept apart in the model: recompute on the snapshot (read-only, exact) */
                                     veto = lazy_probe(s, ibuf, l->pos + 1 + j2, mlen, j2 == 0 ? lazy1 : lazy2);
                                 } else if (fix && level == 0 && !lconf[j2]) {
                                     /* depth-1 probe: the chain head is the newest accepted start with the probe's key, else the snapshot's */
                                     const int m = mlen - 3, pp = l->pos + 1;
-                                    if (lhit[j2] >= 0) { veto = le32(ibuf + pp + m) == le32(ibuf + L[lhit[j2]].pos + m); st.lfixes++; }
+                                    if (lhit[j2] > LNONE) { veto = le32(ibuf + pp + m) == le32(ibuf + L[lhit[j2]].pos + m); st.lfixes++; }
                                     else veto = l->lsrc1_valid && le32(ibuf + pp + m) == le32(ibuf + l->lsrc1 + m);
                                 } else if (fix && level > 0 && !lconf[j2] && mlen == l->sp_len && lhits[j2] <= 2) {
                                     /* generic probe: [the newest one or two accepted starts with the probe's key] ++ the first depth - h nodes
                                      * of the snapshot's probe chain; the length is the speculation's, so the snapshot part is known (vpos) */
                                     const int Lp = j2 == 0 ? lazy1 : lazy2, m = mlen - 3, pp = l->pos + 1 + j2;
                                     int h = 0;
-                                    for (int j = g; j >= 0 && h < Lp && !veto; j--) if ((S[j] || j == g) && L[j].canm && L[j].key == l->lkey[j2]) {
+                                    for (int j = g; j >= -ng && h < Lp && !veto; j--) if ((S[j] || j == g) && L[j].canm && L[j].key == l->lkey[j2]) {
                                         if (le32(ibuf + pp + m) == le32(ibuf + L[j].pos + m)) veto = 1;
                                         h++;
                                     }
@@ -397,7 +480,6 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
             st.rounds++; st.iters += it + 1; st.hist_it[it < 15 ? it : 15]++; if (it + 1 > st.maxit) st.maxit = it + 1;
             /* ---- commit S below the limit (sequentially here; the formulas are the kernel's) */
             uint16_t mru_seq[256][2]; memcpy(mru_seq, mru, sizeof mru);     /* sequential emulation of the events, for the assert */
-            int slot_of[MAXNL];
             int ncom = 0, last = -1;
             for (int g = 0; g < limit; g++) if (S[g]) {
                 lane_t* l = &L[g];
@@ -415,16 +497,16 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 uint32_t word;
                 if (l->canm) {
                     zo_bucket* b = &s->bucket[l->ctx];
-                    int k = 0; for (int j = 0; j < g; j++) if (S[j] && L[j].canm && L[j].ctx == l->ctx) k++;
+                    int k = 0; for (int j = -ng; j < g; j++) if (S[j] && L[j].canm && L[j].ctx == l->ctx) k++;
                     const int head = (l->head0 + k + 1) & (ZO_RING - 1);
                     b->head = (uint16_t)((b->head + 1) & (ZO_RING - 1));
                     if (b->head != head) { fprintf(stderr, "head formula mismatch\n"); return -1; }
-                    slot_of[g] = head;
-                    const int link = l->link_lane >= 0 ? slot_of[l->link_lane] : l->node0;
+                    slot_of[g] = head; l->slot = head;
+                    const int link = l->link_lane > LNONE ? slot_of[l->link_lane] : l->node0;
                     if (b->hash[l->hc] != link) { fprintf(stderr, "link mismatch at pos %d: hash head %d, link %d\n", l->pos, b->hash[l->hc], link); return -1; }
                     b->suffix[head] = (uint16_t)link; b->offset[head] = (uint32_t)l->pos | l->chk << 24; b->hash[l->hc] = (uint16_t)head;
                     if (l->ty == TY_MATCH) {
-                        const int mn = l->mnode_slot < 0 ? slot_of[-1 - l->mnode_slot] : l->mnode_slot;
+                        const int mn = l->mnode_slot < 0 ? slot_of[REF_LANE(l->mnode_slot)] : l->mnode_slot;
                         word = (uint32_t)(258 + l->mlen - ZO_MATCH_MIN) | (uint32_t)((head - mn) & (ZO_RING - 1)) << 16;
                     } else word = 0;
                 } else word = 0;
@@ -432,6 +514,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 tok_out[nt++] = word;
                 opos += l->ty == TY_MATCH ? 2 : 1;
                 ncom++; last = g;
+                if (stale) { clog[nlog] = *l; clog[nlog].has_ev = 0; nlog++; }
             }
             /* final MRU state by the kernel's formula: per key, the last event lane writes (s0, s1) */
             for (int g = 0; g < limit; g++) if (S[g] && L[g].has_ev) {
@@ -466,6 +549,13 @@ int main(int argc, char** argv) {
     if (argc > 8) max_tok = atoi(argv[8]);
     if (argc > 9) guess_mru = atoi(argv[9]);
     if (argc > 10) prefix_pct = atoi(argv[10]);
+    if (argc > 11) grid = atoi(argv[11]);
+    if (argc > 12) stale = atoi(argv[12]);
+    if (argc > 13) ghost_cap = atoi(argv[13]);
+    if (argc > 14) ahead_c = atoi(argv[14]);
+    if (argc > 15) ahead_r = atoi(argv[15]);
+    if (stale && !grid) { fprintf(stderr, "stale = 1 needs grid = 1 or 2\n"); return 2; }
+    if (ahead_r > MAXNL) return 2;
     FILE* f = fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 2; }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     if (n > maxb) n = maxb;
@@ -506,5 +596,9 @@ int main(int argc, char** argv) {
            st.rounds, st.tokens, (double)st.committed / (st.rounds ? st.rounds : 1), (double)n / (st.rounds ? st.rounds : 1), (double)st.iters / (st.rounds ? st.rounds : 1), st.maxit,
            (double)st.serial / (st.rounds ? st.rounds : 1), st.hard[1], st.hard[2], st.hard[3], st.fixes, st.lfixes);
     printf("   iterations histogram:"); for (int i = 0; i < 16; i++) printf(" %ld", st.hist_it[i]); printf("\n");
+    if (grid) printf("   grid %d stale %d ghost_cap %d: windows %ld rounds/window %.3f lanes/round %.1f sync rounds %ld (%.1f %% of rounds) ghosts/round %.1f (max %ld, over the cap %ld) "
+                     "chain head is a ghost %ld (%.2f per round) lanes speculated ahead %ld\n", grid, stale, ghost_cap, st.windows, (double)st.rounds / (st.windows ? st.windows : 1),
+                     (double)st.lanes_sum / (st.rounds ? st.rounds : 1), st.sync_rounds, 100.0 * st.sync_rounds / (st.rounds ? st.rounds : 1),
+                     (double)st.ghost_sum / (st.rounds ? st.rounds : 1), st.ghost_max, st.ghost_over, st.ghost_a1, (double)st.ghost_a1 / (st.rounds ? st.rounds : 1), st.spec_lanes);
     return bad;
 }
