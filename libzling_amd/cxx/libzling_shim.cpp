@@ -267,6 +267,9 @@ namespace {
 // OnProcess (src/libzling.cpp:306-336: GetChar, three GetUInt32, GetData(olen) per sub-block, the 0x00 that closes the block), and a
 // handler may itself read from the inputter inside OnProcess -- the Adler32 variant of the demo does (demo/zling.cpp:124-132) --
 // so nothing may be read ahead.  One block per GPU call; the context carries the literal tables from block to block.
+// A bad flag or bad sizes stop the READING of the block, not the decoding of what was read: the reference meets errors in stream
+// order (a sub-block's Huffman stream and replay come before the next sub-block's flag), so the bytes up to and including the
+// offending flag / header go to zlng_decode_blocks, which reports the first error in that order (csrc/decode.hip, k_frame_walk).
 // Returns false on an I/O error (the caller still fires OnDone and returns -1, src/libzling.cpp:421-426).
 bool decode_block_by_block(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
     CtxGuard ctx(make_ctx(0, false, 1));
@@ -275,11 +278,11 @@ bool decode_block_by_block(Inputter* inputter, Outputter* outputter, ActionHandl
     raw.resize(kBlock);
     while (!inputter->IsEnd()) {                                          // src/libzling.cpp:306
         z.clear();
-        bool closed = false;
+        bool closed = false, bad = false;
         while (!inputter->IsEnd()) {                                      // :312
             const int flag = inputter->GetChar();
-            if (flag != 0 && flag != 1) throw std::runtime_error(zlng_strerror(ZLNG_E_FLAG));          // :315-317
             z.push_back((unsigned char)flag);
+            if (flag != 0 && flag != 1) { bad = true; break; }             // :315-317 ("invalid encflag." unless something in front of it fails first)
             if (flag == 0) { closed = true; break; }                       // :318-320
             uint32_t hdr[3];                                               // encpos, rlen, olen (:322-324)
             for (int k = 0; k < 3; k++) {
@@ -287,7 +290,7 @@ bool decode_block_by_block(Inputter* inputter, Outputter* outputter, ActionHandl
                 if (inputter->IsErr()) return false;
                 for (int shift = 24; shift >= 0; shift -= 8) z.push_back((unsigned char)(hdr[k] >> shift & 0xFF));
             }
-            if (hdr[1] > 262144u || hdr[2] > 393216u) throw std::runtime_error(zlng_strerror(ZLNG_E_BLOCKSIZE));   // :326-328
+            if (hdr[1] > 262144u || hdr[2] > 393216u) { bad = true; break; }   // :326-328 ("invalid block size.", likewise)
             const size_t at = z.size(), olen = hdr[2];
             z.resize(at + olen);
             size_t got = 0;
@@ -298,9 +301,9 @@ bool decode_block_by_block(Inputter* inputter, Outputter* outputter, ActionHandl
             if (got < olen) throw std::runtime_error(zlng_strerror(ZLNG_E_TRUNC));   // the reference decodes what its buffer held before
         }
         if (z.empty()) break;
-        if (!closed) z.push_back(0);          // end of input inside a block: the reference's inner loop ends there too (:312) and writes the block
+        if (!closed && !bad) z.push_back(0);  // end of input inside a block: the reference's inner loop ends there too (:312) and writes the block
         size_t used = 0, produced = 0, end = 0;
-        if (z.size() > 1) {
+        if (z.size() > 1 || bad) {
             const int rc = zlng_decode_blocks(ctx.c, z.data(), z.size(), &used, raw.data(), raw.size(), &produced, &end);
             if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
             if (rc != ZLNG_OK) throw std::runtime_error(zlng_strerror(rc));
@@ -318,11 +321,11 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
         handler->SetInputterOutputter(inputter, outputter, false);
         handler->OnInit();
     }
-    const char* ra = getenv("ZLNG_DECODE_READAHEAD");
-    if (handler && !(ra && atoi(ra) != 0)) {
-        // exact pull order (see decode_block_by_block); ZLNG_DECODE_READAHEAD=1 opts a handler that never touches the
-        // inputter into the batched path below
-        decode_block_by_block(inputter, outputter, handler);
+    static const bool readahead = [] { const char* ra = getenv("ZLNG_DECODE_READAHEAD"); return ra && atoi(ra) != 0; }();   // read once per process
+    if (handler && !readahead) {
+        // exact pull order (see decode_block_by_block); ZLNG_DECODE_READAHEAD=1 opts a process whose handlers never touch the
+        // inputter into the batched path below.  (false = an I/O error: reported through IsErr() in the return below, like the reference.)
+        (void)decode_block_by_block(inputter, outputter, handler);
     } else {
         const int nb_full = std::min(batch_blocks(), 64);
         // Small streams are the common case for a library call: start with a 4-block context (the decode pools cost ~80 MB
