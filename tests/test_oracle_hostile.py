@@ -90,3 +90,15 @@ def test_over_subscribed_tables_decode_like_the_reference_two_level_lookup(oracl
         assert tuple(got) == (rc, int(y.size), hashlib.sha256(y.tobytes()).hexdigest()), name
         n_ok += rc == 0
     assert n_ok >= 20                                                   # damaged tables that still decode: the interesting half
+
+
+def test_oracle_decoder_is_memory_safe_on_hostile_streams(oracle):
+    """No reference needed: the restatement's decoder over 4,000 mutants -- every verdict one of its own codes, no more bytes reported
+    than the capacity, and (under scripts/sanitize.sh cpu, which runs this suite on the ASan + UBSan build of the oracle) no read or
+    write outside its buffers, which is the reason its deviation rules exist."""
+    seen = collections.Counter()
+    for name, m, cap in hostile.mutants(oracle, 424242, 4000):
+        rc, y, flags = oracle.decode_ex(m, cap)
+        assert rc in (0, -1, -2, -3, -4, -5, -6, -7, -8) and y.size <= cap and 0 <= flags < 128, (name, rc, flags)
+        seen[rc] += 1
+    assert seen[0] > 100 and seen[-7] > 100 and seen[-8] > 100
