@@ -1,0 +1,30 @@
+#!/bin/bash
+# Everything a round's last GPU call should leave behind, in one gpurun call (run from the repository root on the GPU box):
+#   scripts/round_end.sh r05_f            -> gpurun_out/ (copy what should be kept into profiles/)
+#   1. the GPU test suite                                     (${TAG}_gpu_tests.txt)
+#   2. scripts/profile_round.sh: PMC traffic passes, the default bench line, the rocprofv3 kernel trace of the same command
+#   3. bench.py through torch.distributed.run with 2 and 3 ranks on this one device (ZLNG_BENCH_ONE_DEVICE=1: the N > 1 control flow
+#      over gloo -- RCCL refuses two ranks on one device), every line with parity / roofline / cpu_baseline
+#   4. config 4's per-GPU share (8 GiB at e4) and the decode line
+set -u
+TAG=${1:-r05_x}
+OUT=$PWD/gpurun_out; mkdir -p $OUT
+(time timeout 2400 python -m pytest tests -m gpu -x -q) > $OUT/${TAG}_gpu_tests.txt 2>&1; tail -3 $OUT/${TAG}_gpu_tests.txt
+bash scripts/profile_round.sh $TAG
+export MASTER_ADDR=127.0.0.1
+ZLNG_BENCH_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+    bench.py --gpus 2 --steps 2 --warmup 1 --size 402653184 --no-multistream 2> $OUT/${TAG}_two_ranks.err | grep '^{' > $OUT/${TAG}_two_ranks_one_device.json
+ZLNG_BENCH_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29542 \
+    bench.py --gpus 3 --steps 2 --warmup 1 --size 1000000000 --strong --no-multistream 2> $OUT/${TAG}_three_ranks.err | grep '^{' > $OUT/${TAG}_three_ranks_strong_one_device.json
+python - <<PY
+import json
+for f in ("two_ranks_one_device", "three_ranks_strong_one_device"):
+    try:
+        d = json.load(open("$OUT/${TAG}_%s.json" % f))
+        print(f, d["n_gpus"], d["value"], "parity", d["parity"], d["parity_ranges"]["source"][:40], "alt identical", d["alt_host_rank_chains"]["identical_bytes"])
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
+timeout 900 python bench.py --level 4 --size 8589934592 --steps 1 --warmup 0 --no-multistream > $OUT/${TAG}_config4_share_e4_8GiB_1gpu.json 2> $OUT/${TAG}_config4.err
+timeout 900 python bench.py --decode --size 100000000 > $OUT/${TAG}_decode.json 2> $OUT/${TAG}_decode.err
+tail -c 300 $OUT/${TAG}_config4_share_e4_8GiB_1gpu.json; echo; tail -c 300 $OUT/${TAG}_decode.json
