@@ -158,6 +158,20 @@ def expected_ranges(args, world, single, source, ranges, live_max_bytes):
     return out, "%s-live (the CPU encoder over the whole %d-byte stream on rank 0's host in this run)" % (kind, total)
 
 
+def gather_digests(buf, world, dev):
+    """[(bytes, sha256 hex)] of every rank's buffer, in rank order, on every rank (40 bytes per rank through one all_gather; `dev` is
+    where the backend wants its tensors: "cuda" under RCCL, "cpu" under gloo)."""
+    mine = np.frombuffer(int(buf.size).to_bytes(8, "little") + hashlib.sha256(buf.tobytes()).digest(), dtype=np.uint8)
+    if world == 1:
+        rows = [mine]
+    else:
+        t = torch.from_numpy(mine.copy()).to(dev)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        rows = [q.cpu().numpy() for q in parts]
+    return [(int.from_bytes(r[:8].tobytes(), "little"), r[8:].tobytes().hex()) for r in rows]
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -363,19 +377,8 @@ def main():
     def seg_bytes(sg):
         return np.concatenate([d_out[o:o + k].cpu().numpy() for o, k in sg]) if sg else np.empty(0, np.uint8)
 
-    def gather_digests(buf):
-        mine = np.frombuffer(int(buf.size).to_bytes(8, "little") + hashlib.sha256(buf.tobytes()).digest(), dtype=np.uint8)
-        if world == 1:
-            rows = [mine]
-        else:
-            t = torch.from_numpy(mine.copy()).to(cdev)
-            parts = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)
-            rows = [q.cpu().numpy() for q in parts]
-        return [(int.from_bytes(r[:8].tobytes(), "little"), r[8:].tobytes().hex()) for r in rows]
-
     got = seg_bytes(segs)
-    per_rank = gather_digests(got)
+    per_rank = gather_digests(got, world, cdev)
 
     alt_multi = None
     if world > 1 and single and not args.no_cpu_baseline:
@@ -390,7 +393,7 @@ def main():
         dta = (time.perf_counter() - t1) / max(1, args.steps - 1)
         st_alt = enc.timings()
         enc.set_host_rank_contexts(0)
-        per_rank_alt = gather_digests(seg_bytes(segs_alt))
+        per_rank_alt = gather_digests(seg_bytes(segs_alt), world, cdev)
         ta = torch.tensor([dta, sum(st_alt.get(k, 0.0) for k in RANK_STAGES), st_alt.get("rolz_parse_max", 0.0)], dtype=torch.float64, device=cdev)
         tmax = ta.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = ta.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)

@@ -269,3 +269,33 @@ def test_staggered_launch_times_need_not_be_a_zero_prefix_and_must_match_the_con
     bad = sharding.RangeEncoder(lambda blocks: _LogStream(0, log), 30, 10, stagger=("at", [0.0, 0.1]))
     with pytest.raises(ValueError):
         bad.parse(1 << 40, 30 * BLOCK)
+
+
+def _digest_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    buf = np.frombuffer(bytes([rank + 1]) * (1000 + rank), dtype=np.uint8)
+    q.put((rank, bench.gather_digests(buf, world, "cpu")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gathers_every_ranks_size_and_sha256_on_every_rank():
+    """bench.py's PASS/FAIL column at N > 1 starts from every rank's own size + SHA-256, gathered with one all_gather: three ranks
+    over gloo, each with a different buffer, and every rank must end up with the same, correct list."""
+    import hashlib
+    world, port = 3, 29655
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_digest_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [(1000 + r, hashlib.sha256(bytes([r + 1]) * (1000 + r)).hexdigest()) for r in range(world)]
+    assert res[0] == want and res[1] == want and res[2] == want
