@@ -225,6 +225,10 @@ struct Spec {
     // generic levels, for the workgroup parser's in-window evaluation: best (len | node << 9) over the first depth-1 / depth-2
     // nodes of the chain, and the index of the first node of each probe's chain that vetoes (its depth if none)
     uint32_t pre1, pre2, vpos1, vpos2;
+    // generic levels, ring rule (ZLNG_RING_FIX): ring distance of chain node 0, and for the first three nodes BEHIND it that lie within 64
+    // slots ahead of the bucket's head -- the only ones a round's <= 64 inserts can reach -- distance | (best len | node << 9 over the
+    // nodes in front of that one) << 6; ntail counts all such nodes (more than three: the rule gives up)
+    uint32_t d0g, tail0, tail1, tail2, ntail;
 };
 
 __device__ __forceinline__ uint32_t lcp16(const Quad qa, const Quad qb) {      // 0 if the first 4 bytes differ, 16 = all equal
@@ -323,10 +327,21 @@ __device__ __forceinline__ void speculate_from(Spec& S, uint8_t* dict, const uin
     uint32_t nov, nnx;
     B.node(nx & (kRing - 1), nov, nnx);
     uint32_t pre1 = 0xFFFFFFFFu, pre2 = 0xFFFFFFFFu;                       // (unset: the walk ended before that many nodes)
+    uint32_t d0g = kRing - 1, tail0 = 0, tail1 = 0, tail2 = 0, ntail = 0;
     for (int i = 0; i < cfg.depth && __any(active); i++) {                 // src/libzling_lz.cpp:240-267
         if (i == cfg.depth - 1) pre1 = maxlen | maxnode << kSpNodeShift;       // the first i nodes are in
         if (i == cfg.depth - 2) pre2 = maxlen | maxnode << kSpNodeShift;
         if (active) dmin = min(dmin, ring_dist(node, head0));
+        {   // the ring rule's record of this node (positions fall along the walk, so do the distances: the recorded nodes are its tail)
+            const uint32_t dn = ring_dist(node, head0);
+            if (i == 0 && active) d0g = dn;
+            const bool rec = active && i > 0 && dn < 64u;
+            const uint32_t ent = dn | (maxlen | maxnode << kSpNodeShift) << 6;
+            tail0 = rec && ntail == 0u ? ent : tail0;
+            tail1 = rec && ntail == 1u ? ent : tail1;
+            tail2 = rec && ntail == 2u ? ent : tail2;
+            ntail += rec ? 1u : 0u;
+        }
         const uint32_t off_n = nov & 0xFFFFFF;
         const bool more = active && nx != 65535u && !(off <= off_n);
         const bool cmp_n = more && (nov >> 24) == chk;
@@ -346,6 +361,7 @@ __device__ __forceinline__ void speculate_from(Spec& S, uint8_t* dict, const uin
     uint32_t sp = maxlen | maxnode << kSpNodeShift | kSpCanMatch;
     S.pre1 = pre1 == 0xFFFFFFFFu ? (maxlen | maxnode << kSpNodeShift) : pre1;
     S.pre2 = pre2 == 0xFFFFFFFFu ? (maxlen | maxnode << kSpNodeShift) : pre2;
+    S.d0g = d0g; S.tail0 = tail0; S.tail1 = tail1; S.tail2 = tail2; S.ntail = ntail;
     const bool lz = maxlen >= (uint32_t)kMatchMin && maxlen < (uint32_t)kLazyLimit;
     const uint32_t m = lz ? maxlen - 3u : 0u;
     bool v1 = false, v2 = false;

@@ -60,6 +60,7 @@ struct WSpec {
     uint32_t lsrc1;              // level 0: source offset of the probe's chain head | exists << 31
     uint32_t pre1, pre2;         // levels 1-4: best (len | node << 9) over the first depth-1 / depth-2 chain nodes
     uint32_t vpos1, vpos2;       // levels 1-4: index of the first node of a probe's chain that vetoes (its depth if none)
+    uint32_t d0g, tail0, tail1, tail2, ntail;   // levels 1-4, ring rule: rolz_dev.h Spec
 };
 
 // Level 0 (depth 2, one lazy probe of depth 1; src/libzling_lz.cpp:130), straight-line predicated code: three dependent round
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 S1.sp = kMatchMin - 1; S1.node0 = 65535; S1.head0 = 0; S1.dmin = kRing - 1;
                 S1.lkix1 = S1.lkix2 = S1.lctx1 = S1.lctx2 = 0; S1.lz1 = S1.lz2 = false; S1.ld1 = S1.ld2 = kRing - 1; S1.ov0 = 0;
                 S1.pre1 = S1.pre2 = kMatchMin - 1; S1.vpos1 = S1.vpos2 = 0;
+                S1.d0g = kRing - 1; S1.tail0 = S1.tail1 = S1.tail2 = S1.ntail = 0;
                 if (canm) speculate_from(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk, hd0, hd1, hd2);
                 W.len = S1.sp & kSpLenMask; W.node = (S1.sp >> kSpNodeShift) & (kRing - 1);
                 W.node0 = S1.node0; W.ov0 = S1.ov0; W.dmin = S1.dmin; W.d0 = W.d1 = S1.dmin;
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 W.lkey2 = lkey2;
                 W.ld1 = S1.ld1; W.ld2 = S1.ld2; W.lsrc1 = 0;
                 W.pre1 = S1.pre1; W.pre2 = S1.pre2; W.vpos1 = S1.vpos1; W.vpos2 = S1.vpos2;
+                W.d0g = S1.d0g; W.tail0 = S1.tail0; W.tail1 = S1.tail1; W.tail2 = S1.tail2; W.ntail = S1.ntail;
             }
             const uint32_t head0 = heads[ctx];
             const uint32_t m0c = mru[ctx], m0e = mru[ek];           // MRU slots of my check key / my event key at the start of the round
@@ -679,8 +682,23 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     const bool has_a2 = has_a1 && kq2 != 0ull;
                     const int a2 = has_a2 ? top_bit(kq2 | 1ull) : a1;
                     const bool has_a3 = has_a2 && (kq2 & ~(1ull << a2)) != 0ull;
-                    hard = ecan && (W.dmin <= k || has_a3);
-                    ml = W.len; mn = W.node;
+                    // Ring rule (a.ring_fix; scripts/experiments/wg_parser_model.c ring_fix, exact there at every level): a chain node whose
+                    // slot a token of this round has taken over ENDS the walk in front of it -- the reference reads a later position
+                    // there and its chain-end test stops (src/libzling_lz.cpp:265) -- so the match is the best over the nodes before
+                    // it, which phase 1 recorded for the walk's tail.  Node 0 taken over, a token of the round in my hash slot as well,
+                    // or a tail longer than the record: still hard.  (A slot that was only read for the chain-end test changes nothing.)
+                    const bool ringhit = W.dmin <= k;
+                    bool cut = false;
+                    uint32_t cutpre = W.len | W.node << kSpNodeShift;
+                    if (a.ring_fix != 0 && ecan && ringhit && !has_a1 && W.d0g > k) {
+                        const bool v0 = W.ntail > 0u && (W.tail0 & 63u) <= k, v1 = W.ntail > 1u && (W.tail1 & 63u) <= k, v2 = W.ntail > 2u && (W.tail2 & 63u) <= k;
+                        if (v0) { cut = true; cutpre = W.tail0 >> 6; }
+                        else if (v1) { cut = true; cutpre = W.tail1 >> 6; }
+                        else if (v2) { cut = true; cutpre = W.tail2 >> 6; }
+                        else cut = W.ntail <= 3u;
+                    }
+                    hard = ecan && ((ringhit && !cut) || has_a3);
+                    ml = cutpre & kSpLenMask; mn = (cutpre >> kSpNodeShift) & (kRing - 1);
                     const bool fixl = ecan && !hard && has_a1;
                     if (__any(fixl)) {
                         const uint32_t k1 = t_key[a1], k2 = t_key[a2], la1 = t_lane[a1], la2 = t_lane[a2];

@@ -18,6 +18,7 @@ struct ParseArgs {
     int            min_restart; // levels 1-4: < 0 replays every hard token by the serial code instead of starting the next round at it (ZLNG_MIN_RESTART)
     int            prefix_pct;  // after a round's first iteration: commit the tokens in front of the first changed one instead of iterating when they
                                 // are at least this share (%) of the round's tokens (0: always iterate, the default; ZLNG_PREFIX_PCT)
+    int            ring_fix;    // levels 1-4: a chain node taken over by a token of the round ends the walk in front of it instead of making the token hard (ZLNG_RING_FIX)
     uint32_t       tok_cap;     // token words reserved per block
     uint32_t       blk0;        // first block of this launch (a level-schedule repair re-parses a tail of the range)
     uint32_t*      overflow;    // 1: a block ran out of token words (its output is then incomplete; the host grows the pools once and repeats);

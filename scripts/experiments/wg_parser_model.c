@@ -50,6 +50,8 @@ typedef struct {
     int ty2, tlen2, mlen2, mnode2, link2, hard, hardcls;
     int has_ev, cond, eff; uint32_t s0b;
     int slot;                         /* ring slot the committed token got (ghosts) */
+    /* generic levels, ring_fix: ring distance of chain node i and the best (len, node) over the nodes in front of it */
+    int nn; int nd[17], bl[17], bn[17];
 } lane_t;
 #define LNONE (-(1 << 20))             /* link_lane: no in-round predecessor (lane indices run from -ng: ghosts are negative) */
 #define LANE_REF(a) (-1 - ((a) + MAXG)) /* match source / chain link that is a lane of the round (or a ghost), as a negative "slot" */
@@ -59,6 +61,7 @@ static struct {
     long rounds, tokens, iters, hard[8], serial, committed, cut_rounds, fixes, lfixes, maxit;
     long hist_it[16];
     long prefix_rounds;
+    long ringfixes;
     long windows, sync_rounds, first_rounds, ghost_sum, ghost_max, ghost_over, ghost_a1, spec_lanes, lanes_sum;
 } st;
 
@@ -73,6 +76,10 @@ static int precise_risk = 1, only_s = 0, max_tok = 1 << 30, guess_mru = 0;
  * speculated (a long match jumped over it), falls back to a synchronous phase 1 ("sync round").  Exactness is checked like before:
  * every token against the oracle's, and the commit's head / link formulas against the dictionary. */
 static int grid = 0, stale = 0, ghost_cap = 128;
+/* ring_fix = 1 (levels 1-4, candidate for round 6): a chain node whose slot a token of this round has rewritten ENDS the walk in front of
+ * it (the reference then reads a later position there and its chain-end test stops, src/libzling_lz.cpp:265) -- exact from the running
+ * best phase 1 recorded per node, instead of a hard token.  Node 0 rewritten stays hard. */
+static int ring_fix = 0;
 /* grid = 2: FLOATING windows (a round starts at the next token start, as the kernel's do) with stale = 1: while a round is resolved the
  * positions [P + ahead_c, P + ahead_c + ahead_r) are evaluated ahead; the next round uses them where it lies inside that range and is
  * cut short where the range ends; it is a sync round when it starts in front of the range. */
@@ -88,7 +95,7 @@ static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth
     const zo_bucket* b = &s->bucket[buf[pos - 1]];
     int node = b->hash[hc], head0 = b->head, dmin = ZO_RING - 1;
     o->node0 = node; o->head0 = head0; o->ov0 = node != 65535 ? b->offset[node] : 0; o->has0 = node != 65535;
-    o->len0 = 0; o->d0 = o->d1 = ZO_RING - 1; o->has1 = 0;
+    o->len0 = 0; o->d0 = o->d1 = ZO_RING - 1; o->has1 = 0; o->nn = 0;
     int maxlen = ZO_MATCH_MIN - 1, maxnode = 0;
     int set1 = 0, set2 = 0;
     o->pl[1] = o->pl[2] = ZO_MATCH_MIN - 1; o->pn[1] = o->pn[2] = 0;
@@ -100,6 +107,7 @@ static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth
             if (i == depth - 2 && !set2) { o->pl[2] = maxlen; o->pn[2] = maxnode; set2 = 1; }
             int d = ring_dist(node, head0); if (d < dmin) dmin = d;
             if (i == 0) o->d0 = d;
+            o->nd[i] = d; o->bl[i] = maxlen; o->bn[i] = maxnode; o->nn = i + 1;
             uint32_t off = b->offset[node] & 0xFFFFFF;
             if ((b->offset[node] >> 24) == chk && buf[pos + maxlen] == buf[off + maxlen]) {
                 int len = common_len(buf + pos, buf + off);
@@ -118,6 +126,7 @@ static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth
     if (!set1) { o->pl[1] = maxlen; o->pn[1] = maxnode; }       /* the walk ended before that many nodes */
     if (!set2) { o->pl[2] = maxlen; o->pn[2] = maxnode; }
     o->pl[0] = maxlen; o->pn[0] = maxnode;
+    o->bl[o->nn] = maxlen; o->bn[o->nn] = maxnode;
     o->dmin = dmin; o->sp_len = maxlen; o->sp_node = maxnode;
     int veto = 0;
     const int lz = maxlen >= ZO_MATCH_MIN && maxlen < ZO_LAZY_LIMIT;
@@ -357,7 +366,15 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                         }
                         const int ring0 = l->has0 && l->d0 <= k, ring1 = l->has1 && l->d1 <= k;
                         const int lvl0fix = fix && level == 0;
-                        if (lvl0fix ? (a1 > LNONE ? (a2 == LNONE && ring0) : ring0) : ring) { l->hard = 1; l->hardcls = 2; }
+                        int cutlen = -1, cutnode = 0;
+                        if (ring_fix && !lvl0fix && ring && a1 == LNONE && l->nn > 0 && l->nd[0] > k) {
+                            /* nodes are visited from the newest to the oldest: the first one whose slot has been handed out again ends the walk */
+                            int ic = l->nn;
+                            for (int i = 1; i < l->nn; i++) if (l->nd[i] <= k) { ic = i; break; }
+                            cutlen = l->bl[ic]; cutnode = l->bn[ic];
+                        }
+                        if (cutlen >= 0) { is_match = cutlen >= ZO_MATCH_MIN; mlen = cutlen; mnode = cutnode; st.ringfixes++; }
+                        else if (lvl0fix ? (a1 > LNONE ? (a2 == LNONE && ring0) : ring0) : ring) { l->hard = 1; l->hardcls = 2; }
                         else if (lvl0fix && a1 == LNONE && ring1) {
                             /* node 1's slot was rewritten by a start of this round: it now holds a later position than node 0's,
                              * so the reference's chain-end test (src/libzling_lz.cpp:265) stops the walk after node 0 */
@@ -552,6 +569,7 @@ int main(int argc, char** argv) {
     if (argc > 11) grid = atoi(argv[11]);
     if (argc > 12) stale = atoi(argv[12]);
     if (argc > 13) ghost_cap = atoi(argv[13]);
+    if (getenv("RING_FIX")) ring_fix = atoi(getenv("RING_FIX"));
     if (argc > 14) ahead_c = atoi(argv[14]);
     if (argc > 15) ahead_r = atoi(argv[15]);
     if (stale && !grid) { fprintf(stderr, "stale = 1 needs grid = 1 or 2\n"); return 2; }
@@ -595,6 +613,7 @@ int main(int argc, char** argv) {
            "(key %ld ring %ld lazy %ld) fixes %ld lazyfixes %ld\n", argv[1], NL, level, fix, n, bad ? "MISMATCH" : "exact",
            st.rounds, st.tokens, (double)st.committed / (st.rounds ? st.rounds : 1), (double)n / (st.rounds ? st.rounds : 1), (double)st.iters / (st.rounds ? st.rounds : 1), st.maxit,
            (double)st.serial / (st.rounds ? st.rounds : 1), st.hard[1], st.hard[2], st.hard[3], st.fixes, st.lfixes);
+    if (ring_fix) printf("   ring_fix: %ld walks ended at a rewritten node instead of going hard (%.3f per round)\n", st.ringfixes, (double)st.ringfixes / (st.rounds ? st.rounds : 1));
     printf("   iterations histogram:"); for (int i = 0; i < 16; i++) printf(" %ld", st.hist_it[i]); printf("\n");
     if (grid) printf("   grid %d stale %d ghost_cap %d: windows %ld rounds/window %.3f lanes/round %.1f sync rounds %ld (%.1f %% of rounds) ghosts/round %.1f (max %ld, over the cap %ld) "
                      "chain head is a ghost %ld (%.2f per round) lanes speculated ahead %ld\n", grid, stale, ghost_cap, st.windows, (double)st.rounds / (st.windows ? st.windows : 1),
