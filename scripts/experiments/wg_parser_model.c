@@ -61,7 +61,7 @@ static struct {
     long rounds, tokens, iters, hard[8], serial, committed, cut_rounds, fixes, lfixes, maxit;
     long hist_it[16];
     long prefix_rounds;
-    long ringfixes;
+    long ringfixes, lz_why[4];
     long windows, sync_rounds, first_rounds, ghost_sum, ghost_max, ghost_over, ghost_a1, spec_lanes, lanes_sum;
 } st;
 
@@ -444,7 +444,11 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                                         veto = l->vpos[j2] < Lp - h;
                                     }
                                     st.lfixes++;
-                                } else { need_hard = 1; break; }
+                                } else {
+                                    need_hard = 1;
+                                    if (S[g]) { if (lconf[j2]) st.lz_why[0]++; else if (mlen != l->sp_len) st.lz_why[1]++; else if (lhits[j2] > 2) st.lz_why[2]++; else st.lz_why[3]++; }
+                                    break;
+                                }
                             }
                             if (need_hard) { l->hard = 1; l->hardcls = 3; }
                             else if (veto) is_match = 0;
@@ -613,6 +617,8 @@ int main(int argc, char** argv) {
            "(key %ld ring %ld lazy %ld) fixes %ld lazyfixes %ld\n", argv[1], NL, level, fix, n, bad ? "MISMATCH" : "exact",
            st.rounds, st.tokens, (double)st.committed / (st.rounds ? st.rounds : 1), (double)n / (st.rounds ? st.rounds : 1), (double)st.iters / (st.rounds ? st.rounds : 1), st.maxit,
            (double)st.serial / (st.rounds ? st.rounds : 1), st.hard[1], st.hard[2], st.hard[3], st.fixes, st.lfixes);
+    printf("   lazy-hard causes among tokens of S (per evaluation, not per round cut): probe slot rewritten %ld, length changed %ld, > 2 tokens with the probe's key %ld, other %ld\n",
+           st.lz_why[0], st.lz_why[1], st.lz_why[2], st.lz_why[3]);
     if (ring_fix) printf("   ring_fix: %ld walks ended at a rewritten node instead of going hard (%.3f per round)\n", st.ringfixes, (double)st.ringfixes / (st.rounds ? st.rounds : 1));
     printf("   iterations histogram:"); for (int i = 0; i < 16; i++) printf(" %ld", st.hist_it[i]); printf("\n");
     if (grid) printf("   grid %d stale %d ghost_cap %d: windows %ld rounds/window %.3f lanes/round %.1f sync rounds %ld (%.1f %% of rounds) ghosts/round %.1f (max %ld, over the cap %ld) "

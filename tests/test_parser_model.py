@@ -35,3 +35,16 @@ def test_window_parser_model_is_exact(model, level, mode):
     args = [exe, f, "256", str(level), "1", "99999999999", "1", "0", "64", "0", "0"] + mode
     p = subprocess.run(args, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and ": exact |" in p.stdout, p.stdout[-600:] + p.stderr[-600:]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_ring_rule_is_exact_in_the_model(model, level):
+    """Levels 1-4, the rule the kernel carries behind ZLNG_RING_FIX=1: a chain node whose ring slot a token of the same round has
+    taken over ends the walk in front of it (the reference's chain-end test, src/libzling_lz.cpp:265) -- the match is the best over
+    the nodes before it -- instead of making the token a serially replayed one.  Exact, and it must actually fire."""
+    exe, f = model
+    p = subprocess.run([exe, f, "256", str(level), "1", "99999999999", "1", "0", "64"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RING_FIX="1"))
+    assert p.returncode == 0 and ": exact |" in p.stdout, p.stdout[-600:] + p.stderr[-600:]
+    fired = int(p.stdout.split("ring_fix: ")[1].split()[0])
+    assert fired > 100, p.stdout[-400:]
