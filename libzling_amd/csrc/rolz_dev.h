@@ -408,7 +408,7 @@ __device__ __forceinline__ void lcp_tail2(const uint8_t* a, const uint8_t* b, co
 }
 
 // (The level-0 speculations of the one-wavefront and the pipelined parser -- speculate_l0, speculate_l0w with its "open lane"
-//  convention -- left with those parsers in round 4: scripts/experiments/retired/.  The workgroup-wide parser's level-0 form,
+//  convention -- left with those parsers in round 4 (git history: scripts/experiments/retired/ up to commit 0899800).  The workgroup-wide parser's level-0 form,
 //  speculate_l0t, lives in rolz_wg.hip; the wide slot plane it reads -- a slot's own word + a copy of the word of the slot it
 //  links to, taken when the link was made -- is described at BucketT above and in DESIGN.md, K1.)
 

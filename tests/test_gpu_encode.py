@@ -350,7 +350,7 @@ def test_alternative_parsers_are_bit_exact(parser):
     """The one-lane serial form of the parser (k_rolz_parse_serial, ZLNG_PARSER=serial: the reference's loop token by token) is the
     on-device cross-check of the production parser: same bytes as the oracle at e0 and e4 on text with an incompressible stretch
     and a sub-block cut inside a window.  (Own process: the parser is chosen when the context is created.  The one-wavefront and
-    the pipelined parsers of rounds 1-3 are retired: scripts/experiments/retired/.)"""
+    the pipelined parsers of rounds 1-3 are retired: git history, scripts/experiments/retired/ up to commit 0899800.)"""
     import subprocess
     import sys
     code = r'''
