@@ -62,6 +62,7 @@ static struct {
     long hist_it[16];
     long prefix_rounds;
     long ringfixes, lz_why[4];
+    long open_lanes, open_rounds, open_tok, long_fix_evals, maxtail_sum;   /* long-match statistics (level 0): lanes / tokens with a match of 16 bytes or more */
     long windows, sync_rounds, first_rounds, ghost_sum, ghost_max, ghost_over, ghost_a1, spec_lanes, lanes_sum;
 } st;
 
@@ -295,6 +296,8 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 if (grid) st.sync_rounds++;
             }
             st.lanes_sum += nlive;
+            { int no = 0, mx = 0; for (int g = 0; g < nlive; g++) if (L[g].sp_len >= 16) { no++; if (L[g].sp_len > mx) mx = L[g].sp_len; }
+              st.open_lanes += no; if (no) { st.open_rounds++; st.maxtail_sum += (mx - 16 + 31) / 32; } }
             for (int g = 0; g < nlive; g++) {
                 lane_t* l = &L[g];
                 l->ty = l->sp_match ? TY_MATCH : TY_LIT;
@@ -386,6 +389,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                                 /* chain = [a1, a2 | node0] (depth 2): exact from the window's text */
                                 const uint8_t* p = ibuf + l->pos;
                                 int l1 = L[a1].chk == l->chk ? common_len(p, ibuf + L[a1].pos) : 0;
+                                if (S[g] && l1 >= 16) st.long_fix_evals++;
                                 int l2, n2;
                                 if (a2 > LNONE) { l2 = L[a2].chk == l->chk ? common_len(p, ibuf + L[a2].pos) : 0; n2 = LANE_REF(a2); }
                                 else { l2 = l->has0 ? l->len0 : 0; n2 = l->node0; }
@@ -535,6 +539,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                 tok_out[nt++] = word;
                 opos += l->ty == TY_MATCH ? 2 : 1;
                 ncom++; last = g;
+                if (l->ty == TY_MATCH && l->mlen >= 16) st.open_tok++;
                 if (stale) { clog[nlog] = *l; clog[nlog].has_ev = 0; nlog++; }
             }
             /* final MRU state by the kernel's formula: per key, the last event lane writes (s0, s1) */
@@ -619,6 +624,10 @@ int main(int argc, char** argv) {
            (double)st.serial / (st.rounds ? st.rounds : 1), st.hard[1], st.hard[2], st.hard[3], st.fixes, st.lfixes);
     printf("   lazy-hard causes among tokens of S (per evaluation, not per round cut): probe slot rewritten %ld, length changed %ld, > 2 tokens with the probe's key %ld, other %ld\n",
            st.lz_why[0], st.lz_why[1], st.lz_why[2], st.lz_why[3]);
+    printf("   long matches: lanes with a speculative match >= 16 bytes %.1f per round (in %.1f %% of the rounds; longest tail %.2f 32-byte trips per such round), "
+           "committed tokens >= 16 bytes %.2f per round, same-slot fixes against a >= 16-byte candidate %.2f per round\n",
+           (double)st.open_lanes / (st.rounds ? st.rounds : 1), 100.0 * st.open_rounds / (st.rounds ? st.rounds : 1), (double)st.maxtail_sum / (st.open_rounds ? st.open_rounds : 1),
+           (double)st.open_tok / (st.rounds ? st.rounds : 1), (double)st.long_fix_evals / (st.rounds ? st.rounds : 1));
     if (ring_fix) printf("   ring_fix: %ld walks ended at a rewritten node instead of going hard (%.3f per round)\n", st.ringfixes, (double)st.ringfixes / (st.rounds ? st.rounds : 1));
     printf("   iterations histogram:"); for (int i = 0; i < 16; i++) printf(" %ld", st.hist_it[i]); printf("\n");
     if (grid) printf("   grid %d stale %d ghost_cap %d: windows %ld rounds/window %.3f lanes/round %.1f sync rounds %ld (%.1f %% of rounds) ghosts/round %.1f (max %ld, over the cap %ld) "
