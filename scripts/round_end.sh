@@ -5,7 +5,7 @@
 #   2. scripts/profile_round.sh: PMC traffic passes, the default bench line, the rocprofv3 kernel trace of the same command
 #   3. bench.py through torch.distributed.run with 2 and 3 ranks on this one device (ZLNG_BENCH_ONE_DEVICE=1: the N > 1 control flow
 #      over gloo -- RCCL refuses two ranks on one device), every line with parity / roofline / cpu_baseline
-#   4. config 4's per-GPU share (8 GiB at e4) and the decode line
+#   4. config 4's per-GPU share (8 GiB at e4), one 4 GiB stream at e0 (longer than a context), the decode line
 set -u
 TAG=${1:-r05_x}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
@@ -26,5 +26,8 @@ for f in ("two_ranks_one_device", "three_ranks_strong_one_device"):
         print(f, "FAILED", e)
 PY
 timeout 900 python bench.py --level 4 --size 8589934592 --steps 1 --warmup 0 --no-multistream > $OUT/${TAG}_config4_share_e4_8GiB_1gpu.json 2> $OUT/${TAG}_config4.err
+# one e0 stream longer than a context: 4 GiB through 2 contexts of 128 blocks, the second parse beside the first rank stage
+timeout 900 python bench.py --size 4294967296 --steps 2 --warmup 1 --no-multistream --no-realtext > $OUT/${TAG}_long_stream_e0_4GiB_1gpu.json 2> $OUT/${TAG}_long.err
+tail -c 200 $OUT/${TAG}_long_stream_e0_4GiB_1gpu.json; echo
 timeout 900 python bench.py --decode --size 100000000 > $OUT/${TAG}_decode.json 2> $OUT/${TAG}_decode.err
 tail -c 300 $OUT/${TAG}_config4_share_e4_8GiB_1gpu.json; echo; tail -c 300 $OUT/${TAG}_decode.json
