@@ -29,5 +29,6 @@ timeout 900 python bench.py --level 4 --size 8589934592 --steps 1 --warmup 0 --n
 # one e0 stream longer than a context: 4 GiB through 2 contexts of 128 blocks, the second parse beside the first rank stage
 timeout 900 python bench.py --size 4294967296 --steps 2 --warmup 1 --no-multistream --no-realtext > $OUT/${TAG}_long_stream_e0_4GiB_1gpu.json 2> $OUT/${TAG}_long.err
 tail -c 200 $OUT/${TAG}_long_stream_e0_4GiB_1gpu.json; echo
+timeout 600 python scripts/multi_stream_probe.py 4 > $OUT/${TAG}_four_streams_one_gpu.json 2> $OUT/${TAG}_four_streams.err; tail -c 300 $OUT/${TAG}_four_streams_one_gpu.json; echo
 timeout 900 python bench.py --decode --size 100000000 > $OUT/${TAG}_decode.json 2> $OUT/${TAG}_decode.err
 tail -c 300 $OUT/${TAG}_config4_share_e4_8GiB_1gpu.json; echo; tail -c 300 $OUT/${TAG}_decode.json
