@@ -102,3 +102,68 @@ def test_oracle_decoder_is_memory_safe_on_hostile_streams(oracle):
         assert rc in (0, -1, -2, -3, -4, -5, -6, -7, -8) and y.size <= cap and 0 <= flags < 128, (name, rc, flags)
         seen[rc] += 1
     assert seen[0] > 100 and seen[-7] > 100 and seen[-8] > 100
+
+
+def _brev(v, bits):
+    return int(format(v, "0%db" % bits)[::-1], 2) if bits else 0
+
+
+def _lut_entry_exact(i, lens, limit, fast):
+    """csrc/decode.hip lut_entry_exact, restated: the decode-table entry of index i computed -- not filled -- from the symbols of every
+    length in symbol order: of a length's symbols whose code matches i, the largest; any length <= `fast` in front of the longer ones."""
+    best_fast = best_slow = -1
+    code = 0
+    for L in range(1, limit + 1):
+        syms = [c for c, l in enumerate(lens) if l == L]
+        start = code
+        code = (code + len(syms)) * 2
+        if not syms:
+            continue
+        m = (1 << L) - 1
+        q = _brev(i & m, L)
+        k0 = (q - start) & m
+        if k0 >= len(syms):
+            continue
+        c = syms[k0 + (((len(syms) - 1 - k0) >> L) << L)]
+        if L <= fast:
+            best_fast = max(best_fast, c)
+        else:
+            best_slow = max(best_slow, c)
+    return best_fast if best_fast >= 0 else (best_slow if best_slow >= 0 else 0xFFFF)
+
+
+def test_computed_decode_table_entries_equal_the_reference_fill_order(oracle):
+    """The HIP decoder cannot FILL the decode table of an over-subscribed length set the way the reference does (symbols in order, a
+    later one overwriting an earlier one, src/libzling_huffman.cpp:140-153: lanes would race), so k_huff_decode computes each entry
+    (lut_entry_exact).  The same formula in Python against tables filled in the reference's order from the oracle's own codes
+    (ZlingMakeEncodeTable restated), with the 10-bit fast table in front for alphabet 1 (src/libzling.cpp:361, 376-379): random
+    over-, under- and exactly subscribed sets of both alphabets, every entry."""
+    rng = np.random.Generator(np.random.PCG64(31))
+
+    def filled(lens, limit, bits):
+        codes = oracle.encode_table(np.asarray(lens, np.uint32), limit)
+        lut = [0xFFFF] * (1 << bits)
+        for c, l in enumerate(lens):
+            if 0 < l <= bits:
+                for i in range(int(codes[c]), 1 << bits, 1 << l):
+                    lut[i] = c
+        return lut
+    for trial in range(40):
+        n, limit, fast = (514, 15, 10) if trial % 2 == 0 else (32, 8, 8)
+        kind = trial % 5
+        if kind == 0: lens = rng.integers(0, 16, n)
+        elif kind == 1: lens = np.where(rng.random(n) < 0.1, rng.integers(1, 6, n), 0)
+        elif kind == 2: lens = np.where(rng.random(n) < 0.5, rng.integers(8, 16, n), 0)
+        elif kind == 3: lens = np.full(n, int(rng.integers(1, 16)))
+        else: lens = np.where(rng.random(n) < 0.03, rng.integers(1, 16, n), 0)
+        lens = [int(v) for v in lens]
+        full = filled(lens, limit, limit)
+        if n == 514:
+            fast_t = filled(lens, limit, fast)
+            want = [fast_t[i & ((1 << fast) - 1)] if fast_t[i & ((1 << fast) - 1)] != 0xFFFF else full[i] for i in range(1 << limit)]
+            idx = rng.integers(0, 1 << limit, 600)
+        else:
+            want = full
+            idx = range(1 << limit)
+        for i in idx:
+            assert _lut_entry_exact(int(i), lens, limit, fast) == want[int(i)], (trial, int(i))
