@@ -301,7 +301,7 @@ __device__ __forceinline__ void speculate_heads(uint8_t* dict, const LevelCfg cf
 __device__ __forceinline__ void speculate_from(Spec& S, uint8_t* dict, const uint8_t* buf, uint32_t head0, uint32_t lhead1, uint32_t lhead2,
                                                uint32_t risk_dist, int pos,
                                                const LevelCfg cfg, const Quad qa, uint32_t ctx, uint32_t hc, uint32_t chk,
-                                               const uint32_t node0, const uint32_t ln1, const uint32_t ln2) {
+                                               const uint32_t node0, const uint32_t ln1, const uint32_t ln2, const bool ring_rec = false) {
     const uint32_t w4 = qa.a;                        // qa: bytes pos .. pos+15, loaded by the caller (pos+275 < ilen)
     const bool want1 = cfg.lazy1 > 0, want2 = cfg.lazy2 > 0;
     const uint32_t lctx1 = w4 & 0xFF, lctx2 = (w4 >> 8) & 0xFF;
@@ -332,7 +332,7 @@ __device__ __forceinline__ void speculate_from(Spec& S, uint8_t* dict, const uin
         if (i == cfg.depth - 1) pre1 = maxlen | maxnode << kSpNodeShift;       // the first i nodes are in
         if (i == cfg.depth - 2) pre2 = maxlen | maxnode << kSpNodeShift;
         if (active) dmin = min(dmin, ring_dist(node, head0));
-        {   // the ring rule's record of this node (positions fall along the walk, so do the distances: the recorded nodes are its tail)
+        if (ring_rec) {   // the ring rule's record of this node (positions fall along the walk, so do the distances: the recorded nodes are its tail)
             const uint32_t dn = ring_dist(node, head0);
             if (i == 0 && active) d0g = dn;
             const bool rec = active && i > 0 && dn < 64u;

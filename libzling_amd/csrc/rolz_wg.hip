@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 S1.lkix1 = S1.lkix2 = S1.lctx1 = S1.lctx2 = 0; S1.lz1 = S1.lz2 = false; S1.ld1 = S1.ld2 = kRing - 1; S1.ov0 = 0;
                 S1.pre1 = S1.pre2 = kMatchMin - 1; S1.vpos1 = S1.vpos2 = 0;
                 S1.d0g = kRing - 1; S1.tail0 = S1.tail1 = S1.tail2 = S1.ntail = 0;
-                if (canm) speculate_from(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk, hd0, hd1, hd2);
+                if (canm) speculate_from(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk, hd0, hd1, hd2, a.ring_fix != 0);
                 W.len = S1.sp & kSpLenMask; W.node = (S1.sp >> kSpNodeShift) & (kRing - 1);
                 W.node0 = S1.node0; W.ov0 = S1.ov0; W.dmin = S1.dmin; W.d0 = W.d1 = S1.dmin;
                 W.has0 = S1.node0 != 65535u; W.has1 = false; W.len0 = 0;
