@@ -5,7 +5,7 @@ to that role: for every mutant on which none of the oracle's own rules fired (fl
 run in a forked child, because on hostile input it may read or write memory it does not own -- must reach the same verdict (the
 same exception message class, src/libzling.cpp:316, 327, 382, 392, 399, 407, or success) and must have written the same bytes
 (on success all of them; on an error the complete blocks in front of it).  Where a rule did fire the reference's behaviour is
-only counted: those are the documented deviations (DESIGN.md section 8)."""
+only counted: those are the documented deviations (DESIGN.md section 6)."""
 import collections
 import hashlib
 import os
