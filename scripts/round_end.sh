@@ -6,6 +6,7 @@
 #   3. bench.py through torch.distributed.run with 2 and 3 ranks on this one device (ZLNG_BENCH_ONE_DEVICE=1: the N > 1 control flow
 #      over gloo -- RCCL refuses two ranks on one device), every line with parity / roofline / cpu_baseline
 #   4. config 4's per-GPU share (8 GiB at e4), one 4 GiB stream at e0 (longer than a context), the decode line
+#   5. scripts/ring_fix_ab.sh ring-only: the GPU suite and the e1/e4 lines with ZLNG_RING_FIX=1 against the same without it
 set -u
 TAG=${1:-r05_x}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
@@ -32,3 +33,5 @@ tail -c 200 $OUT/${TAG}_long_stream_e0_4GiB_1gpu.json; echo
 timeout 600 python scripts/multi_stream_probe.py 4 > $OUT/${TAG}_four_streams_one_gpu.json 2> $OUT/${TAG}_four_streams.err; tail -c 300 $OUT/${TAG}_four_streams_one_gpu.json; echo
 timeout 900 python bench.py --decode --size 100000000 > $OUT/${TAG}_decode.json 2> $OUT/${TAG}_decode.err
 tail -c 300 $OUT/${TAG}_config4_share_e4_8GiB_1gpu.json; echo; tail -c 300 $OUT/${TAG}_decode.json
+echo
+RING_ONLY=1 bash scripts/ring_fix_ab.sh $TAG
