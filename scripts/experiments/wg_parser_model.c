@@ -38,6 +38,7 @@ typedef struct {
     int sp_match, sp_len, sp_node, node0, head0, dmin, sp_veto;
     uint32_t ov0;
     uint32_t lkey[2]; int lctx[2], lrisk[2], lwant[2], ld[2];
+    int ldfull[2];                     /* lazy_fix: min ring distance over the first lazy-depth nodes of the probe's chain, whatever vetoes */
     int d0, d1, has1;
     int pl[3], pn[3];      /* generic levels: best (len, node) over the first depth-1 / depth-2 chain nodes ([1], [2]; [0] = all) */
     int vpos[2], lhit2[2]; /* generic levels: index of the first snapshot node that vetoes probe j (its depth if none) */
@@ -61,7 +62,7 @@ static struct {
     long rounds, tokens, iters, hard[8], serial, committed, cut_rounds, fixes, lfixes, maxit;
     long hist_it[16];
     long prefix_rounds;
-    long ringfixes, lz_why[4];
+    long ringfixes, lazyfixes2, lz_why[4];
     long open_lanes, open_rounds, open_tok, long_fix_evals, maxtail_sum;   /* long-match statistics (level 0): lanes / tokens with a match of 16 bytes or more */
     long windows, sync_rounds, first_rounds, ghost_sum, ghost_max, ghost_over, ghost_a1, spec_lanes, lanes_sum;
 } st;
@@ -81,6 +82,11 @@ static int grid = 0, stale = 0, ghost_cap = 128;
  * it (the reference then reads a later position there and its chain-end test stops, src/libzling_lz.cpp:265) -- exact from the running
  * best phase 1 recorded per node, instead of a hard token.  Node 0 rewritten stays hard. */
 static int ring_fix = 0;
+/* lazy_fix = 1 (levels 1-4, candidate, model only): a token whose match length is no longer the speculation's (a token of the round is its
+ * chain's head, or the ring rule cut its walk) has its lazy probes walked AGAIN under the new length -- the newest <= 2 tokens of the round with
+ * the probe's key, then the first lazy-depth - h nodes of the snapshot's probe chain (src/libzling_lz.cpp:291-316) -- instead of going hard;
+ * valid while no ring slot among the first lazy-depth nodes of that chain has been handed out again (ldfull). */
+static int lazy_fix = 0;
 /* grid = 2: FLOATING windows (a round starts at the next token start, as the kernel's do) with stale = 1: while a round is resolved the
  * positions [P + ahead_c, P + ahead_c + ahead_r) are evaluated ahead; the next round uses them where it lies inside that range and is
  * cut short where the range ends; it is a sync round when it starts in front of the range. */
@@ -156,6 +162,19 @@ static void speculate(const zo_stream* s, const uint8_t* buf, int pos, int depth
             }
         } else if (n != 65535) { int d = ring_dist(n, lb->head); if (d < ld) ld = d; }   /* (level-0 fix may need the probe later) */
         o->lrisk[j] = ld < risk_dist; o->ld[j] = ld;
+        {   /* lazy_fix: the same walk without the veto's early exit */
+            int n2 = lb->hash[hh], lf = ZO_RING - 1;
+            for (int i = 0; n2 != 65535 && i < ldepth[j]; i++) {
+                int d = ring_dist(n2, lb->head); if (d < lf) lf = d;
+                uint32_t off = lb->offset[n2] & 0xFFFFFF;
+                int nx = lb->suffix[n2];
+                if (nx == 65535) break;
+                d = ring_dist(nx, lb->head); if (d < lf) lf = d;
+                if (off <= (lb->offset[nx] & 0xFFFFFF)) break;
+                n2 = nx;
+            }
+            o->ldfull[j] = lf;
+        }
     }
     o->sp_veto = veto;
     o->sp_match = maxlen >= ZO_MATCH_MIN && !(lz && veto);
@@ -358,7 +377,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                     if (l->canm) {
                         const int ring = l->dmin <= k;
                         /* lazy read sets: accepted starts <= g (own insert included, src/libzling_lz.cpp:271) */
-                        int lconf[2] = {0, 0}, lhit[2] = {LNONE, LNONE}, lhits[2] = {0, 0};
+                        int lconf[2] = {0, 0}, lconff[2] = {0, 0}, lhit[2] = {LNONE, LNONE}, lhits[2] = {0, 0};
                         for (int j2 = 0; j2 < 2; j2++) if (l->lwant[j2]) {
                             int cnt = 0;
                             for (int j = g; j >= -ng; j--) if (S[j] || j == g) if (L[j].canm) {
@@ -366,6 +385,7 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                                 if ((int)L[j].ctx == l->lctx[j2]) cnt++;
                             }
                             lconf[j2] = precise_risk ? cnt > l->ld[j2] : (l->lrisk[j2] && cnt > 0);   /* a visited ring slot at distance d is rewritten by the (d+1)-th insert */
+                            lconff[j2] = cnt > l->ldfull[j2];
                         }
                         const int ring0 = l->has0 && l->d0 <= k, ring1 = l->has1 && l->d1 <= k;
                         const int lvl0fix = fix && level == 0;
@@ -448,6 +468,16 @@ static int parse_block_model(zo_stream* s, const uint8_t* ibuf, int ilen, int le
                                         veto = l->vpos[j2] < Lp - h;
                                     }
                                     st.lfixes++;
+                                } else if (lazy_fix && fix && level > 0 && mlen != l->sp_len && !lconff[j2] && lhits[j2] <= 2) {
+                                    /* changed length: the probe walked again under it */
+                                    const int Lp = j2 == 0 ? lazy1 : lazy2, m = mlen - 3, pp = l->pos + 1 + j2;
+                                    int h = 0;
+                                    for (int j = g; j >= -ng && h < Lp && !veto; j--) if ((S[j] || j == g) && L[j].canm && L[j].key == l->lkey[j2]) {
+                                        if (le32(ibuf + pp + m) == le32(ibuf + L[j].pos + m)) veto = 1;
+                                        h++;
+                                    }
+                                    if (!veto && h < Lp) veto = lazy_probe(s, ibuf, pp, mlen, Lp - h);
+                                    st.lazyfixes2++;
                                 } else {
                                     need_hard = 1;
                                     if (S[g]) { if (lconf[j2]) st.lz_why[0]++; else if (mlen != l->sp_len) st.lz_why[1]++; else if (lhits[j2] > 2) st.lz_why[2]++; else st.lz_why[3]++; }
@@ -579,6 +609,7 @@ int main(int argc, char** argv) {
     if (argc > 12) stale = atoi(argv[12]);
     if (argc > 13) ghost_cap = atoi(argv[13]);
     if (getenv("RING_FIX")) ring_fix = atoi(getenv("RING_FIX"));
+    if (getenv("LAZY_FIX")) lazy_fix = atoi(getenv("LAZY_FIX"));
     if (argc > 14) ahead_c = atoi(argv[14]);
     if (argc > 15) ahead_r = atoi(argv[15]);
     if (stale && !grid) { fprintf(stderr, "stale = 1 needs grid = 1 or 2\n"); return 2; }
@@ -628,6 +659,7 @@ int main(int argc, char** argv) {
            "committed tokens >= 16 bytes %.2f per round, same-slot fixes against a >= 16-byte candidate %.2f per round\n",
            (double)st.open_lanes / (st.rounds ? st.rounds : 1), 100.0 * st.open_rounds / (st.rounds ? st.rounds : 1), (double)st.maxtail_sum / (st.open_rounds ? st.open_rounds : 1),
            (double)st.open_tok / (st.rounds ? st.rounds : 1), (double)st.long_fix_evals / (st.rounds ? st.rounds : 1));
+    if (lazy_fix) printf("   lazy_fix: %ld probes walked again under a changed length instead of going hard (%.3f per round)\n", st.lazyfixes2, (double)st.lazyfixes2 / (st.rounds ? st.rounds : 1));
     if (ring_fix) printf("   ring_fix: %ld walks ended at a rewritten node instead of going hard (%.3f per round)\n", st.ringfixes, (double)st.ringfixes / (st.rounds ? st.rounds : 1));
     printf("   iterations histogram:"); for (int i = 0; i < 16; i++) printf(" %ld", st.hist_it[i]); printf("\n");
     if (grid) printf("   grid %d stale %d ghost_cap %d: windows %ld rounds/window %.3f lanes/round %.1f sync rounds %ld (%.1f %% of rounds) ghosts/round %.1f (max %ld, over the cap %ld) "

@@ -48,3 +48,16 @@ def test_ring_rule_is_exact_in_the_model(model, level):
     assert p.returncode == 0 and ": exact |" in p.stdout, p.stdout[-600:] + p.stderr[-600:]
     fired = int(p.stdout.split("ring_fix: ")[1].split()[0])
     assert fired > 100, p.stdout[-400:]
+
+
+@pytest.mark.parametrize("level", [2, 4])
+def test_lazy_rule_is_exact_in_the_model(model, level):
+    """Model only (LABNOTES, round 5's last session): a token whose match length is no longer the speculation's has its lazy probes
+    walked again under the new length (src/libzling_lz.cpp:291-316) instead of going hard.  Exact on top of the ring rule; it buys
+    -2.6 % rounds at e4 for about one more probe walk per round, which is why no kernel carries it."""
+    exe, f = model
+    p = subprocess.run([exe, f, "256", str(level), "1", "99999999999", "1", "0", "64"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RING_FIX="1", LAZY_FIX="1"))
+    assert p.returncode == 0 and ": exact |" in p.stdout, p.stdout[-600:] + p.stderr[-600:]
+    fired = int(p.stdout.split("lazy_fix: ")[1].split()[0])
+    assert fired > 100, p.stdout[-400:]
