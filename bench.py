@@ -31,7 +31,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 # A range that goes through several contexts (BASELINE config 4: 512 blocks per GPU = 4 contexts) gives every context its own HIP
 # stream; the runtime maps user streams onto a few hardware queues by default, and a parse that is ordered behind another
@@ -45,6 +44,7 @@ import torch.distributed as dist
 
 import libzling_amd as zl
 from libzling_amd import sharding
+from libzling_amd.textgen import textgen
 
 BLOCK = zl.BLOCK
 METRIC = "encode MB/s (input) at e0 on enwik9; bit-exact .zlng; 1/2/4/8 GPU"
@@ -76,12 +76,22 @@ def load_input(n, first_chunk):
     for path in cands:
         if path and os.path.exists(path) and first_chunk == 0 and os.path.getsize(path) >= n:
             return np.fromfile(path, dtype=np.uint8, count=n), os.path.basename(path)
-    from oracle_py import textgen      # generator lives in libzling_amd/host; oracle_py only binds it
     return textgen(n, first_chunk), "synthetic"
 
 
+def checker():
+    """The CPU checker (oracle/: the restatement and, where built, the real reference) -- test infrastructure, imported only by
+    the legs that report it: cpu_baseline*, rank_chain's host column, the live parity column.  The timed step, the workload
+    generator and the pinned parity column never touch it: `--no-cpu-baseline --no-multistream` runs with oracle/ absent."""
+    odir = os.path.join(ROOT, "oracle")
+    if odir not in sys.path:
+        sys.path.insert(0, odir)
+    import oracle_py
+    return oracle_py.Oracle, oracle_py.Reference
+
+
 def cpu_encoder():
-    from oracle_py import Oracle, Reference
+    Oracle, Reference = checker()
     return (Reference(), "reference") if Reference.available() else (Oracle(), "port")
 
 
@@ -194,7 +204,6 @@ def cpu_multistream(level, mib=128):
     """SURVEY 8(d)'s context line: the reference is single-threaded and ONE stream cannot use more than one core, but a host
     has many -- K independent streams of `mib` MiB (textgen chunks far apart) on K threads, aggregate MB/s.  K = min(cores, 16)."""
     import threading
-    from oracle_py import textgen
     cores = os.cpu_count() or 1
     k = max(1, min(cores, 16))
     cpu, kind = cpu_encoder()
@@ -220,7 +229,7 @@ def rank_chain_line(x, level, hot_literals_gpu, mtf_ms):
     """ns per literal of the hottest context's serial rank chain (src/libzling_lz.cpp:112-117): on the GPU (stage time / that
     context's literals -- the stage is bounded by its longest chain) and on one host core (the reference's own
     ZlingMTFEncoder over the same context's literals of the first 32 MiB)."""
-    from oracle_py import Oracle, Reference
+    Oracle, Reference = checker()
     o = Oracle()
     lits = []
     for b in range(min(2, (x.size + BLOCK - 1) // BLOCK)):
@@ -628,7 +637,7 @@ def bench_decode(args, world, rank, local):
                         "traffic": None, "algorithmic_bytes": int(alg)},
            "stage_ms": {k: round(v, 3) for k, v in stage.items()}, "round_trip": ok}
     if not args.no_cpu_baseline:
-        from oracle_py import Oracle, Reference
+        Oracle, Reference = checker()
         nblk_s = max(1, min(nb, (args.cpu_sample_mib << 20) // BLOCK))
         zs = z[: ends[nblk_s - 1]]
         want = min(n, nblk_s * BLOCK)

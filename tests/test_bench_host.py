@@ -144,3 +144,32 @@ def test_expected_ranges_uses_the_pins_for_the_driver_configuration(manifest):
     want, src = bench.expected_ranges(A, 4, True, "synthetic", sharding.plan(A.size, 4), 0)
     assert src.startswith("pins") and sum(k for k, _ in want) == manifest["config3_enwik9_shape"]["zlng_bytes"]
     assert bench.expected_ranges(A, 4, True, "enwik9", sharding.plan(A.size, 4), 0)[0] is None      # a real file has no pins
+
+
+def test_bench_makes_its_workload_without_the_checker():
+    """bench.py binds the text generator from libzling_amd itself; oracle/ is imported only by the legs that
+    report the checker (cpu_baseline*, rank_chain's host column, live parity).  A fresh interpreter whose import system refuses
+    anything from oracle/ imports bench, makes the workload and resolves the pinned parity column."""
+    import subprocess
+    code = r'''
+import sys, os, importlib.abc
+ROOT = %r
+class Refuse(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path=None, target=None):
+        if name in ("oracle_py", "oracle"):
+            raise ImportError("the checker is not available in this process: " + name)
+sys.meta_path.insert(0, Refuse())
+sys.path.insert(0, ROOT)
+import bench
+assert not any(os.path.basename(p.rstrip("/")) == "oracle" for p in sys.path), sys.path
+x, src = bench.load_input(1 << 20, 0)
+assert src == "synthetic" and x.size == 1 << 20 and x[:64].tobytes().isascii()
+y, _ = bench.load_input(1 << 16, 7)
+assert y.size == 1 << 16 and not (x[: 1 << 16] == y).all()
+class A: level = 0; size = 1_000_000_000; strong = False; no_cpu_baseline = True
+want, why = bench.expected_ranges(A, 1, True, "synthetic", [(0, 1_000_000_000)], 0)
+assert want and len(want[0][1]) == 64 and why.startswith("pins"), why
+print("ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
