@@ -23,6 +23,13 @@
 namespace baidu {
 namespace zling {
 
+// Extension (no counterpart in the reference; callers that do not use it compile and behave as before): an ActionHandler that
+// ALSO inherits this tag promises that its OnProcess never reads from the Inputter while decoding.  Decode() then need not keep
+// the reference's exact pull order (src/libzling.cpp:306-336: nothing is read ahead of the block handed to OnProcess -- the
+// Adler32 handler of demo/zling.cpp:124-132 relies on it) and reads ahead / decodes several blocks per GPU call.  A per-call
+// trait of the handler object; the environment variable ZLNG_DECODE_READAHEAD=0|1 overrides it for a whole process.
+struct DecodeReadAhead {};
+
 int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* action_handler = NULL, int level = 0);
 int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* action_handler = NULL);
 

@@ -9,6 +9,7 @@
 // blocks are parsed concurrently; per_block_out_end lets the bytes and callbacks still be emitted
 // block by block in stream order.
 #include <algorithm>
+#include <cstring>
 #include <future>
 #include <memory>
 #include <string>
@@ -125,6 +126,30 @@ struct RawBuf {
     void resize(size_t bytes) { p.reset(new unsigned char[bytes]); n = bytes; }
     unsigned char* data() { return p.get(); }
     size_t size() const { return n; }
+};
+
+// Growable byte buffer that does not zero-fill what it hands out (std::vector::resize would memset every payload before the
+// read overwrites it) and keeps its storage across clear().
+struct ByteBuf {
+    std::unique_ptr<unsigned char[]> p;
+    size_t n = 0, cap = 0;
+    void clear() { n = 0; }
+    size_t size() const { return n; }
+    unsigned char* data() { return p.get(); }
+    unsigned char* grow(size_t k) {                      // k more bytes at the end; returns where they start
+        if (n + k > cap) {
+            size_t c = std::max(n + k, std::max<size_t>(cap * 2, 1u << 20));
+            std::unique_ptr<unsigned char[]> q(new unsigned char[c]);
+            if (n) memcpy(q.get(), p.get(), n);
+            p.swap(q);
+            cap = c;
+        }
+        unsigned char* at = p.get() + n;
+        n += k;
+        return at;
+    }
+    void push(unsigned char b) { *grow(1) = b; }
+    void append(const unsigned char* src, size_t k) { memcpy(grow(k), src, k); }
 };
 
 struct EncodeSlot {
@@ -263,6 +288,22 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
 
 namespace {
 
+// Blocks in a run of .zlng bytes, by hopping the sub-block headers (flag, encpos, rlen, olen: src/libzling.cpp:312-324); a tail
+// that is not a whole block counts as one.  Sizing only: the decoder itself validates every field.
+size_t blocks_left(const unsigned char* z, size_t n) {
+    size_t blocks = 0, p = 0;
+    bool open = false;
+    while (p < n) {
+        if (z[p] == 0) { blocks++; p++; open = false; continue; }
+        if (z[p] != 1 || n - p < 13) { open = true; break; }
+        const size_t olen = (size_t)z[p + 9] << 24 | (size_t)z[p + 10] << 16 | (size_t)z[p + 11] << 8 | z[p + 12];
+        open = true;
+        if (olen > n - p - 13) break;
+        p += 13 + olen;
+    }
+    return blocks + (open ? 1 : 0);
+}
+
 // Decode with an ActionHandler installed: the reference pulls exactly the bytes a block consists of before it calls
 // OnProcess (src/libzling.cpp:306-336: GetChar, three GetUInt32, GetData(olen) per sub-block, the 0x00 that closes the block), and a
 // handler may itself read from the inputter inside OnProcess -- the Adler32 variant of the demo does (demo/zling.cpp:124-132) --
@@ -273,40 +314,46 @@ namespace {
 // Returns false on an I/O error (the caller still fires OnDone and returns -1, src/libzling.cpp:421-426).
 bool decode_block_by_block(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
     CtxGuard ctx(make_ctx(0, false, 1));
-    std::vector<unsigned char> z;
+    ByteBuf z;                                                            // one block's compressed bytes; its storage is reused from block to block
     RawBuf raw;
     raw.resize(kBlock);
     while (!inputter->IsEnd()) {                                          // src/libzling.cpp:306
         z.clear();
         bool closed = false, bad = false;
+        int bad_code = ZLNG_E_FLAG;
         while (!inputter->IsEnd()) {                                      // :312
             const int flag = inputter->GetChar();
-            z.push_back((unsigned char)flag);
-            if (flag != 0 && flag != 1) { bad = true; break; }             // :315-317 ("invalid encflag." unless something in front of it fails first)
+            z.push((unsigned char)flag);
+            if (flag != 0 && flag != 1) { bad = true; bad_code = ZLNG_E_FLAG; break; }   // :315-317 ("invalid encflag." unless something in front of it fails first)
             if (flag == 0) { closed = true; break; }                       // :318-320
             uint32_t hdr[3];                                               // encpos, rlen, olen (:322-324)
+            unsigned char hb[12];
             for (int k = 0; k < 3; k++) {
                 hdr[k] = inputter->GetUInt32();
                 if (inputter->IsErr()) return false;
-                for (int shift = 24; shift >= 0; shift -= 8) z.push_back((unsigned char)(hdr[k] >> shift & 0xFF));
+                for (int j = 0; j < 4; j++) hb[4 * k + j] = (unsigned char)(hdr[k] >> (24 - 8 * j) & 0xFF);
             }
-            if (hdr[1] > 262144u || hdr[2] > 393216u) { bad = true; break; }   // :326-328 ("invalid block size.", likewise)
-            const size_t at = z.size(), olen = hdr[2];
-            z.resize(at + olen);
+            z.append(hb, sizeof hb);
+            if (hdr[1] > 262144u || hdr[2] > 393216u) { bad = true; bad_code = ZLNG_E_BLOCKSIZE; break; }   // :326-328 ("invalid block size.", likewise)
+            const size_t olen = hdr[2];
+            unsigned char* dst = z.grow(olen);                              // uninitialised: every byte of it is read into below or the call throws
             size_t got = 0;
             while (!inputter->IsEnd() && got < olen) {                     // :329-332
-                got += inputter->GetData(z.data() + at + got, olen - got);
+                got += inputter->GetData(dst + got, olen - got);
                 if (inputter->IsErr()) return false;
             }
             if (got < olen) throw std::runtime_error(zlng_strerror(ZLNG_E_TRUNC));   // the reference decodes what its buffer held before
         }
-        if (z.empty()) break;
-        if (!closed && !bad) z.push_back(0);  // end of input inside a block: the reference's inner loop ends there too (:312) and writes the block
+        if (z.size() == 0) break;
+        if (!closed && !bad) z.push(0);       // end of input inside a block: the reference's inner loop ends there too (:312) and writes the block
         size_t used = 0, produced = 0, end = 0;
         if (z.size() > 1 || bad) {
             const int rc = zlng_decode_blocks(ctx.c, z.data(), z.size(), &used, raw.data(), raw.size(), &produced, &end);
             if (rc == ZLNG_E_NOMEM) throw std::bad_alloc();
             if (rc != ZLNG_OK) throw std::runtime_error(zlng_strerror(rc));
+            // The buffer ended in a flag / header that is not one: whatever the library made of the bytes in front of it (it reports
+            // the first error in stream order, which is normally this very one), the stream does not go on behind it.
+            if (bad) throw std::runtime_error(zlng_strerror(bad_code));
         }
         if (!push_all(outputter, raw.data(), produced)) return false;      // :412-415
         handler->OnProcess(raw.data(), produced);                          // :417-419
@@ -321,10 +368,12 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
         handler->SetInputterOutputter(inputter, outputter, false);
         handler->OnInit();
     }
-    static const bool readahead = [] { const char* ra = getenv("ZLNG_DECODE_READAHEAD"); return ra && atoi(ra) != 0; }();   // read once per process
+    // Per call: a handler that is also a baidu::zling::DecodeReadAhead (libzling.h) promises never to touch the inputter inside
+    // OnProcess and takes the batched path; ZLNG_DECODE_READAHEAD=0|1, read at every call, overrides the handler's trait either way.
+    const char* ra = getenv("ZLNG_DECODE_READAHEAD");
+    const bool readahead = ra ? atoi(ra) != 0 : (handler && dynamic_cast<DecodeReadAhead*>(handler) != nullptr);
     if (handler && !readahead) {
-        // exact pull order (see decode_block_by_block); ZLNG_DECODE_READAHEAD=1 opts a process whose handlers never touch the
-        // inputter into the batched path below.  (false = an I/O error: reported through IsErr() in the return below, like the reference.)
+        // exact pull order (see decode_block_by_block).  (false = an I/O error: reported through IsErr() in the return below, like the reference.)
         (void)decode_block_by_block(inputter, outputter, handler);
     } else {
         const int nb_full = std::min(batch_blocks(), 64);
@@ -377,13 +426,18 @@ int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* handler) {
             }
             zoff += used;
             total_out += produced;
-            if (nb < nb_full && total_out >= (size_t)nb * kBlock) {      // the stream has filled the small context once over: it is long, take the full-size one
+            // The stream has filled this context once over: take a larger one -- four times the blocks per step (4, 16, 64: a
+            // context's pools cost ~10 ms per block to create, so a 6-block stream must not pay for 64), and when the input has
+            // ended, no more than the blocks that are left (counted by hopping the headers of the unconsumed bytes).
+            int nb_next = std::min(nb_full, nb * 4);
+            if (eof) nb_next = std::min(nb_next, std::max(nb, (int)std::min<size_t>(blocks_left(z.data() + zoff, z.size() - zoff), (size_t)nb_full)));
+            if (nb_next > nb && total_out >= (size_t)nb * kBlock) {
                 std::vector<unsigned char> st(ZLNG_MTF_STATE);
                 int lv = 0;                                               // (current_level: an encoder-side scalar, carried by the state call, unused here)
                 if (zlng_get_state(ctx.c, st.data(), &lv) != ZLNG_OK) throw std::runtime_error(zlng_strerror(ZLNG_E_DEVICE));
                 zlng_destroy(ctx.c);
                 ctx.c = nullptr;
-                nb = nb_full;
+                nb = nb_next;
                 ctx.c = make_ctx(0, false, nb);
                 if (zlng_set_state(ctx.c, st.data(), 0) != ZLNG_OK) throw std::runtime_error(zlng_strerror(ZLNG_E_DEVICE));
                 raw.resize((size_t)nb * kBlock);

@@ -485,6 +485,27 @@ static int block_is_complete(const uint8_t* in, size_t n, size_t ip) {
     }
 }
 
+/* Decoder state that outlives a block: the 256 literal tables (src/libzling_lz.cpp:119-121: set up once per decoder object, never
+ * reset).  Everything else -- ring buckets, word MRU, the block buffer -- is per block or per sub-block and lives in the scratch. */
+struct zo_dstream {
+    uint8_t mtf[256][256];
+    zo_dbucket bk[256];
+    uint16_t tb[ZO_SUBBLOCK_SYMS + ZO_SENTINEL];
+    uint8_t blk[ZO_BLOCK_IN + ZO_SENTINEL + 512];
+    uint8_t pay[ZO_PAYLOAD_MAX + ZO_SENTINEL + 16];
+    uint16_t lut1[1 << ZO_MAXLEN1];
+};
+
+zo_dstream* zo_dstream_new(void) {
+    tables_init();
+    zo_dstream* d = (zo_dstream*)calloc(1, sizeof(zo_dstream));
+    if (d) for (int c = 0; c < 256; c++) memcpy(d->mtf[c], zo_mtfinit, 256);     /* src/libzling_lz.cpp:119-121 */
+    return d;
+}
+void zo_dstream_free(zo_dstream* d) { free(d); }
+void zo_dstream_get_mtf(const zo_dstream* d, uint8_t t[256 * 256]) { memcpy(t, d->mtf, 256 * 256); }
+void zo_dstream_set_mtf(zo_dstream* d, const uint8_t t[256 * 256]) { memcpy(d->mtf, t, 256 * 256); }
+
 /* src/libzling.cpp:293-427 Decode + src/libzling_lz.cpp:318-399 ZlingRolzDecoder.
  *
  * On a VALID stream this is the reference, statement by statement.  On a hostile one the reference has behaviour that no
@@ -506,23 +527,24 @@ static int block_is_complete(const uint8_t* in, size_t n, size_t ip) {
  *                    the reference (:369-374) -- the symbols decoded from there on may differ
  * Everything else -- bad flags, sizes over the limits, codes without a symbol in either alphabet, over-subscribed length sets
  * (last symbol in table order wins, with the 10-bit fast table of :361, 376-379 in front of the 15-bit one), indices >= 4096,
- * lengths that miss encpos -- is the reference's own behaviour and is restated exactly. */
-int zo_decode_ex(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, uint32_t* flags_out) {
-    tables_init();
-    zo_dbucket* bk = (zo_dbucket*)malloc(sizeof(zo_dbucket) * 256);
-    uint8_t (*mtf)[256] = (uint8_t(*)[256])malloc(256 * 256);
-    uint16_t* tb = (uint16_t*)malloc(sizeof(uint16_t) * (ZO_SUBBLOCK_SYMS + ZO_SENTINEL));
-    uint8_t* blk = (uint8_t*)malloc(ZO_BLOCK_IN + ZO_SENTINEL + 512);
-    uint8_t* pay = (uint8_t*)calloc(1, ZO_PAYLOAD_MAX + ZO_SENTINEL + 16);
-    uint16_t* lut1 = (uint16_t*)malloc(sizeof(uint16_t) << ZO_MAXLEN1);
+ * lengths that miss encpos -- is the reference's own behaviour and is restated exactly.
+ * (Test infrastructure, like everything in this file: never linked into or called by the product.) */
+
+/* One pass of the reference's outer loop (src/libzling.cpp:306-420): the block that starts at in[*ipp].  On success the block's
+ * bytes are d->blk[0 .. *size) and *ipp stands behind its 0x00 (or at n).  On an error the tables are NOT rolled back (the
+ * reference throws and its decoder object dies with the call); zo_dstream_decode_block below does that for callers that go on. */
+static int decode_one_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* ipp, int* size, uint32_t* flagsp) {
+    zo_dbucket* bk = d->bk;
+    uint8_t (*mtf)[256] = d->mtf;
+    uint16_t* tb = d->tb;
+    uint8_t* blk = d->blk;
+    uint8_t* pay = d->pay;
+    uint16_t* lut1 = d->lut1;
     uint16_t lut1f[1 << ZO_MAXLEN1_FAST];
     int rc = ZO_E_OK;
-    uint32_t flags = 0;
-    size_t ip = 0, op = 0;
-    if (!bk || !mtf || !tb || !blk || !pay || !lut1) { rc = ZO_E_CAP; goto done; }
-    for (int c = 0; c < 256; c++) memcpy(mtf[c], zo_mtfinit, 256);     /* src/libzling_lz.cpp:119-121 */
-
-    while (ip < n) {                                                    /* one output block */
+    uint32_t flags = *flagsp;
+    size_t ip = *ipp;
+    {
         int decpos = 0;
         if (!block_is_complete(in, n, ip)) { flags |= ZO_DEV_TRUNC; rc = ZO_E_TRUNC; goto done; }
         for (int c = 0; c < 256; c++) { memset(bk[c].offset, 0, sizeof bk[c].offset); bk[c].head = 0; }
@@ -629,12 +651,47 @@ int zo_decode_ex(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* 
             if ((uint32_t)opos != encpos) { rc = ZO_E_LZ; goto done; }
             decpos = opos;
         }
+        *size = decpos;
+    }
+done:
+    *ipp = ip;
+    *flagsp = flags;
+    return rc;
+}
+
+int zo_dstream_decode_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* ip, uint8_t* out, size_t cap, size_t* out_len, uint32_t* flags_out) {
+    static uint8_t saved[256][256];                                    /* (the checker is single-threaded per process in the tests that use this) */
+    uint32_t flags = 0;
+    size_t p = *ip;
+    int size = 0;
+    *out_len = 0;
+    memcpy(saved, d->mtf, sizeof saved);
+    int rc = decode_one_block(d, in, n, &p, &size, &flags);
+    if (rc == ZO_E_OK && (size_t)size > cap) rc = ZO_E_CAP;
+    if (flags_out) *flags_out = flags;
+    if (rc != ZO_E_OK) { memcpy(d->mtf, saved, sizeof saved); return rc; }
+    memcpy(out, d->blk, (size_t)size);
+    *out_len = (size_t)size;
+    *ip = p;
+    return ZO_E_OK;
+}
+
+int zo_decode_ex(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, uint32_t* flags_out) {
+    zo_dstream* d = zo_dstream_new();
+    int rc = ZO_E_OK;
+    uint32_t flags = 0;
+    size_t ip = 0, op = 0;
+    if (!d) { rc = ZO_E_CAP; goto done; }
+    while (ip < n) {                                                    /* one output block */
+        int decpos = 0;
+        rc = decode_one_block(d, in, n, &ip, &decpos, &flags);
+        if (rc != ZO_E_OK) goto done;
         if (op + (size_t)decpos > cap) { rc = ZO_E_CAP; goto done; }
-        memcpy(out + op, blk, (size_t)decpos);
+        memcpy(out + op, d->blk, (size_t)decpos);
         op += (size_t)decpos;
     }
 done:
-    free(bk); free(mtf); free(tb); free(blk); free(pay); free(lut1);
+    zo_dstream_free(d);
     *out_len = op;
     if (flags_out) *flags_out = flags;
     return rc;

@@ -15,7 +15,8 @@
 
 namespace {
 
-struct Progress : baidu::zling::ActionHandler {
+// (DecodeReadAhead: OnProcess below only reads the two byte counters, never the stream, so Decode may read ahead)
+struct Progress : baidu::zling::ActionHandler, baidu::zling::DecodeReadAhead {
     std::chrono::steady_clock::time_point t0;
     baidu::zling::FileInputter* in;
     baidu::zling::FileOutputter* out;
