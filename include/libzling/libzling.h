@@ -30,6 +30,20 @@ namespace zling {
 // trait of the handler object; the environment variable ZLNG_DECODE_READAHEAD=0|1 overrides it for a whole process.
 struct DecodeReadAhead {};
 
+// Extension, per call like the above: an ActionHandler that ALSO inherits this says where ONE Encode() call runs and how.
+//   devices / ndevices   the HIP devices the stream is spread over, contiguous block ranges per batch (an index may repeat: several
+//                        contexts on one GPU); overrides ZLNG_DEVICES / ZLNG_DEVICE for this call.  NULL / 0: the environment decides.
+//   host_rank_contexts   k > 0: the k longest literal-rank chains of every range are walked by host threads while the device walks the
+//                        others (zlng_group_set_host_rank_contexts; DESIGN.md section 7: the mode that pays on several GPUs); 0: all on
+//                        the device (the default); -1: leave it to ZLNG_HOST_RANK_CONTEXTS.
+// The bytes produced are the same in every setting.
+struct EncodePlacement {
+    const int* devices;
+    int ndevices;
+    int host_rank_contexts;
+    EncodePlacement() : devices(NULL), ndevices(0), host_rank_contexts(-1) {}
+};
+
 int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* action_handler = NULL, int level = 0);
 int Decode(Inputter* inputter, Outputter* outputter, ActionHandler* action_handler = NULL);
 

@@ -114,6 +114,14 @@ int zlng_encode_parse_after(zlng_ctx* ctx, zlng_ctx* first);
 int zlng_encode_parse(zlng_ctx*, const uint8_t* in, size_t in_len);
 int zlng_encode_finish(zlng_ctx*, uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
 
+/* zlng_encode_finish in two halves, for a driver that finishes several contexts in stream order (zlng_group_encode_finish): _staged
+ * runs rank + Huffman + framing and leaves the bytes in the context's own HBM staging buffer -- the stream state the range leaves
+ * (zlng_get_state) is final when it returns, so the next context's finish can start --, zlng_encode_copy_out then brings exactly
+ * those `n` bytes to the host (blocking; may be called from another thread while OTHER contexts work: it touches only this one).
+ * out_cap bounds what the range may produce, like zlng_encode_finish's (ZLNG_E_CAP leaves the range pending and the state as it was). */
+int zlng_encode_finish_staged(zlng_ctx*, size_t out_cap, size_t* out_len, size_t* per_block_out_end);
+int zlng_encode_copy_out(zlng_ctx*, uint8_t* out, size_t n);
+
 /* Stream state hand-off: 65,536 bytes of MTF tables (context-major) + current_level (0, or the context's level:
  * src/libzling.cpp:261-266 -- anything else is rejected). */
 int zlng_get_state(zlng_ctx*, uint8_t mtf[ZLNG_MTF_STATE], int* current_level);

@@ -102,6 +102,7 @@ struct zlng_ctx {
     const uint8_t* pending_in = nullptr;
     size_t pending_len = 0;
     uint32_t pending_blocks = 0;
+    size_t staged_len = 0;            // bytes zlng_encode_finish_staged left in d_out for zlng_encode_copy_out
 
     StageTimer timer;
     int parser_kind = 3;              // 3 = workgroup-wide window parser (rolz_wg.hip; default), 1 = serial cross-check form (ZLNG_PARSER=serial)
@@ -659,6 +660,33 @@ int zlng_encode_finish(zlng_ctx* c, uint8_t* out, size_t out_cap, size_t* out_le
     CTX_HIP(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
     CTX_HIP(hipStreamSynchronize(c->stream));
     *out_len = produced;
+    return ZLNG_OK;
+}
+
+// The two halves of zlng_encode_finish, for a driver that finishes several contexts in stream order (zlng_group.hip): the stream
+// state a range leaves is final when the first half returns, so the next context's rank stage can start while this one's bytes
+// are still crossing PCIe (the second half, a blocking copy that may run on another thread: it touches only this context).
+int zlng_encode_finish_staged(zlng_ctx* c, size_t out_cap, size_t* out_len, size_t* per_block_out_end) {
+    if (!c || !c->pending_in || !out_len) return ZLNG_E_ARG;
+    *out_len = 0;
+    c->staged_len = 0;
+    const size_t bound = zlng_encode_bound(c->pending_len);
+    const int rc0 = ensure_out(c, bound);
+    if (rc0 != ZLNG_OK) return rc0;
+    size_t produced = 0;
+    const int rc = zlng_encode_finish_device(c, c->d_out, std::min(bound, out_cap), &produced, per_block_out_end);
+    if (rc != ZLNG_OK) return rc;
+    c->staged_len = produced;
+    *out_len = produced;
+    return ZLNG_OK;
+}
+int zlng_encode_copy_out(zlng_ctx* c, uint8_t* out, size_t n) {
+    if (!c || !out || n != c->staged_len) return ZLNG_E_ARG;
+    if (n == 0) return ZLNG_OK;
+    CTX_HIP(hipSetDevice(c->device));                   // (the calling thread may be a helper that has never touched this device)
+    CTX_HIP(hipMemcpyAsync(out, c->d_out, n, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(hipStreamSynchronize(c->stream));
+    c->staged_len = 0;
     return ZLNG_OK;
 }
 

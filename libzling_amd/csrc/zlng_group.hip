@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/zlng.h"
@@ -108,30 +109,45 @@ int zlng_group_encode_parse(zlng_group* g, const uint8_t* in, size_t in_len) {
     return ZLNG_OK;
 }
 
+// Members finish in stream order (the tables and the level travel member to member), but a member's BYTES are not part of that
+// chain: its finish leaves them in its own staging buffer (zlng_encode_finish_staged) and a helper thread brings them to the host
+// (zlng_encode_copy_out) while the next member's rank stage already runs.  The last active member's copy has nothing left to hide
+// behind and runs on the caller's thread.
 int zlng_group_encode_finish(zlng_group* g, uint8_t* out, size_t out_cap, size_t* out_len, size_t* per_block_out_end) {
     if (!g || !g->pending_len || !out || !out_len) return ZLNG_E_ARG;
     *out_len = 0;
     size_t produced = 0, blk0 = 0;
     std::vector<uint8_t> mtf = g->mtf;                 // committed to the group only when every member succeeded
     int level = g->current_level;
-    for (size_t m = 0; m < g->member.size(); m++) {
+    const size_t nm = g->member.size();
+    size_t last = 0;
+    for (size_t m = 0; m < nm; m++) if (g->part_len[m]) last = m;
+    std::vector<std::thread> copies;
+    std::vector<int> copy_rc(nm, ZLNG_OK);
+    auto join_all = [&] { for (std::thread& t : copies) t.join(); copies.clear(); };
+    for (size_t m = 0; m < nm; m++) {
         const size_t len = g->part_len[m];
         if (!len) continue;
         zlng_ctx* c = g->member[m];
         int rc = zlng_set_state(c, mtf.data(), level);
         size_t n = 0;
         size_t* ends = per_block_out_end ? per_block_out_end + blk0 : nullptr;
-        if (rc == ZLNG_OK) rc = zlng_encode_finish(c, out + produced, out_cap - produced, &n, ends);
+        if (rc == ZLNG_OK) rc = zlng_encode_finish_staged(c, out_cap - produced, &n, ends);
         if (rc == ZLNG_OK) rc = zlng_get_state(c, mtf.data(), &level);
-        if (rc != ZLNG_OK) { g->pending_len = 0; return rc; }   // the group's stream state is unchanged: submit the range again
+        if (rc != ZLNG_OK) { join_all(); g->pending_len = 0; return rc; }   // the group's stream state is unchanged: submit the range again
+        uint8_t* dst = out + produced;
+        if (m == last) copy_rc[m] = zlng_encode_copy_out(c, dst, n);
+        else copies.emplace_back([c, dst, n, m, &copy_rc] { copy_rc[m] = zlng_encode_copy_out(c, dst, n); });
         const size_t nblk = (len + kBlock - 1) / kBlock;
         if (ends) for (size_t b = 0; b < nblk; b++) ends[b] += produced;
         produced += n;
         blk0 += nblk;
     }
+    join_all();
+    g->pending_len = 0;
+    for (size_t m = 0; m < nm; m++) if (copy_rc[m] != ZLNG_OK) return copy_rc[m];
     g->mtf.swap(mtf);
     g->current_level = level;
-    g->pending_len = 0;
     *out_len = produced;
     return ZLNG_OK;
 }

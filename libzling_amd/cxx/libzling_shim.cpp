@@ -211,7 +211,11 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
     }
     bool bad_level = level < 0 || level > 4;     // the reference would emit a corrupt stream
     if (!bad_level) {
-        const std::vector<int> devices = pick_devices();
+        // where and how this call runs: a per-call trait of the handler (EncodePlacement, libzling.h) in front of the environment
+        const EncodePlacement* place = handler ? dynamic_cast<EncodePlacement*>(handler) : nullptr;
+        const std::vector<int> devices = (place && place->devices && place->ndevices > 0)
+                                             ? std::vector<int>(place->devices, place->devices + place->ndevices) : pick_devices();
+        const int host_chains = place ? place->host_rank_contexts : -1;
         const int ndev = (int)devices.size();
         const int per_member = std::max(1, batch_blocks());
         const int nb = per_member * ndev;                 // blocks per batch: every device gets `per_member` of them
@@ -229,7 +233,10 @@ int Encode(Inputter* inputter, Outputter* outputter, ActionHandler* handler, int
             s.ends.resize((size_t)nb);
         };
         auto prepare_ctx = [&](EncodeSlot& s, bool stream_ended) {
-            if (!s.grp) s.grp = make_group(devices, level, stream_ended ? std::max((s.have + ndev - 1) / ndev, 1) : per_member);
+            if (!s.grp) {
+                s.grp = make_group(devices, level, stream_ended ? std::max((s.have + ndev - 1) / ndev, 1) : per_member);
+                if (host_chains >= 0) throw_rc(zlng_group_set_host_rank_contexts(s.grp, host_chains));
+            }
         };
         std::vector<unsigned char> state(ZLNG_MTF_STATE);
         int state_level = level;

@@ -96,6 +96,20 @@ class Oracle:
         rc = self.lib.zo_decode_ex(_ptr(a) if a.size else None, a.size, _ptr(out), cap, C.byref(n), C.byref(fl))
         return rc, out[: n.value].copy(), int(fl.value)
 
+    def decode_stats(self, z, cap):
+        """(rc, dict): what the decode reached (zo_dstats, zlng_oracle.h)."""
+        class St(C.Structure):
+            _fields_ = [("max_inserts_one_context", C.c_uint32), ("max_distance", C.c_uint32), ("matches", C.c_uint64),
+                        ("matches_in_wrapped_ring", C.c_uint64), ("beyond_window", C.c_uint64), ("far_matches", C.c_uint64),
+                        ("dst_straddles_64k", C.c_uint64), ("src_straddles_64k", C.c_uint64), ("scratch", C.c_uint32 * 256)]
+        a = np.ascontiguousarray(z)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n = C.c_size_t(0)
+        st = St()
+        self.lib.zo_decode_stats.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(St)]
+        rc = self.lib.zo_decode_stats(_ptr(a), a.size, _ptr(out), cap, C.byref(n), C.byref(st))
+        return rc, {k: int(getattr(st, k)) for k, _ in St._fields_[:8]}
+
     # ---- stage API -------------------------------------------------------------------
     def parse_block(self, block, level=0, apply_mtf=False, stream=None):
         """Parse one <=16 MiB block.  Returns (tokens u32, cuts[(tok_end, encpos, rlen)])."""

@@ -523,12 +523,21 @@ void zo_dstream_set_mtf(zo_dstream* d, const uint8_t t[256 * 256]) { memcpy(d->m
  *                    lengths up to 3,841 past the buffer's sentinel): ZO_E_LZ
  *   ZO_DEV_SELF      a match with ring index 0 (names the slot the token itself has just written, lz.cpp:388-399: the copy's
  *                    source is the destination, i.e. bytes no one has written): ZO_E_LZ
+ *   ZO_DEV_ENTRIES   the sub-blocks of one block hold more than 16 Mi + 64 u16 entries (every entry stands for at least one output
+ *                    byte, so such a block cannot land on its encpos: the reference, which sizes nothing by the block's entries,
+ *                    still decodes the Huffman stream of the sub-block that crosses the limit before its replay fails, and a damaged
+ *                    table there is "bad code" to it): ZO_E_LZ at that sub-block's header, its Huffman stream unread -- the HIP
+ *                    decoder sizes its token pool by this bound (csrc/decode.hip, k_frame_walk `too_many`)
  *   ZO_DEV_OVERREAD  (no rejection) the bit reader consumed bits behind the payload's end: zeros here, stale obuf bytes in
  *                    the reference (:369-374) -- the symbols decoded from there on may differ
  * Everything else -- bad flags, sizes over the limits, codes without a symbol in either alphabet, over-subscribed length sets
  * (last symbol in table order wins, with the 10-bit fast table of :361, 376-379 in front of the 15-bit one), indices >= 4096,
  * lengths that miss encpos -- is the reference's own behaviour and is restated exactly.
  * (Test infrastructure, like everything in this file: never linked into or called by the product.) */
+
+/* What a decode reached (tests/hostile.py's "big structures" streams are checked to reach them): set by zo_decode_stats around a
+ * plain decode, never read by the decoder itself. */
+static __thread zo_dstats* g_stats = NULL;
 
 /* One pass of the reference's outer loop (src/libzling.cpp:306-420): the block that starts at in[*ipp].  On success the block's
  * bytes are d->blk[0 .. *size) and *ipp stands behind its 0x00 (or at n).  On an error the tables are NOT rolled back (the
@@ -546,8 +555,10 @@ static int decode_one_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* 
     size_t ip = *ipp;
     {
         int decpos = 0;
+        uint64_t blk_entries = 0;                                       /* u16 entries of the sub-blocks of this block so far */
         if (!block_is_complete(in, n, ip)) { flags |= ZO_DEV_TRUNC; rc = ZO_E_TRUNC; goto done; }
         for (int c = 0; c < 256; c++) { memset(bk[c].offset, 0, sizeof bk[c].offset); bk[c].head = 0; }
+        if (g_stats) memset(g_stats->inserts_scratch, 0, sizeof g_stats->inserts_scratch);
         while (ip < n) {
             int flag = in[ip++];
             if (flag != 0 && flag != 1) { rc = ZO_E_FLAG; goto done; }  /* :315-317 */
@@ -561,6 +572,8 @@ static int decode_one_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* 
                 rc = ZO_E_BLOCKSIZE; goto done;
             }
             if (olen < ZO_TABLE_BYTES) { flags |= ZO_DEV_SHORT; rc = ZO_E_LZ; goto done; }
+            if (blk_entries + rlen > (uint64_t)ZO_BLOCK_IN + 64) { flags |= ZO_DEV_ENTRIES; rc = ZO_E_LZ; goto done; }
+            blk_entries += rlen;
             memcpy(pay, in + ip, olen);
             memset(pay + olen, 0, 16);
             ip += olen;
@@ -620,6 +633,10 @@ static int decode_one_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* 
                 zo_dbucket* b = &bk[blk[opos - 1]];
                 b->head = (uint16_t)((b->head + 1) & (ZO_RING - 1));   /* GetMatchAndUpdate :388-399 */
                 b->offset[b->head] = (uint32_t)opos;
+                if (g_stats) {
+                    uint32_t* cnt = g_stats->inserts_scratch;
+                    if (++cnt[blk[opos - 1]] > g_stats->max_inserts_one_context) g_stats->max_inserts_one_context = cnt[blk[opos - 1]];
+                }
                 if (v < 256) {
                     uint8_t* t = mtf[blk[opos - 1]];                     /* ZlingMTFDecoder::Decode :122-126 */
                     uint8_t c = t[v], nx = g_mtfnext[v];
@@ -641,6 +658,16 @@ static int decode_one_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* 
                     ti += 2;
                     if (idx == 0) { flags |= ZO_DEV_SELF; rc = ZO_E_LZ; goto done; }
                     uint32_t src = b->offset[(b->head - idx) & (ZO_RING - 1)];
+                    if (g_stats) {
+                        const uint32_t dist = (uint32_t)opos - src;
+                        g_stats->matches++;
+                        if (dist > g_stats->max_distance) g_stats->max_distance = dist;
+                        if (dist > 131072) g_stats->far_matches++;
+                        if (dist > 65536) g_stats->beyond_window++;
+                        if (((uint32_t)opos >> 16) != (((uint32_t)opos + (uint32_t)mlen - 1) >> 16)) g_stats->dst_straddles_64k++;
+                        if ((src >> 16) != ((src + (uint32_t)mlen - 1) >> 16)) g_stats->src_straddles_64k++;
+                        if (g_stats->inserts_scratch[blk[opos - 1]] > ZO_RING && idx > 0) g_stats->matches_in_wrapped_ring++;
+                    }
                     for (int k = 0; k < mlen; k++) blk[opos + k] = blk[src + k];   /* :91-104 forward copy */
                     opos += mlen;
                     uint16_t w = (uint16_t)(blk[opos - 2] << 8 | blk[opos - 1]);
@@ -694,6 +721,14 @@ done:
     zo_dstream_free(d);
     *out_len = op;
     if (flags_out) *flags_out = flags;
+    return rc;
+}
+
+int zo_decode_stats(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, zo_dstats* st) {
+    memset(st, 0, sizeof *st);
+    g_stats = st;
+    const int rc = zo_decode_ex(in, n, out, cap, out_len, NULL);
+    g_stats = NULL;
     return rc;
 }
 

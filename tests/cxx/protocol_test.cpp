@@ -191,6 +191,32 @@ int main(int argc, char** argv) {
         const int rc = baidu::zling::Decode(&in, &out, nullptr);
         printf("  \"decode_no_handler\": {\"rc\": %d, \"same_as_input\": %s}\n", rc, (out.dst == x) ? "true" : "false");
     }
+    // 6. per-call traits of the handler (libzling.h): an Encode spread over two contexts of device 0 with the four longest rank
+    //    chains on host threads produces the same bytes; a Decode whose handler is a DecodeReadAhead takes the batched path
+    //    (several blocks per call: the inputter stands far behind block 0 at the first OnProcess) and the same output
+    {
+        struct Placed : baidu::zling::ActionHandler, baidu::zling::EncodePlacement {};
+        static const int devs[2] = {0, 0};
+        Placed h; h.devices = devs; h.ndevices = 2; h.host_rank_contexts = 4;
+        MemInputter in(x, 21); MemOutputter out(22);
+        std::string threw;
+        int rc = -2;
+        try { rc = baidu::zling::Encode(&in, &out, &h, level); } catch (const std::exception& e) { threw = e.what(); }
+        printf("  ,\"encode_placement\": {\"rc\": %d, \"threw\": \"%s\", \"same_bytes\": %s}\n", rc, threw.c_str(), (out.dst == z) ? "true" : "false");
+    }
+    {
+        struct Ahead : baidu::zling::ActionHandler, baidu::zling::DecodeReadAhead {
+            MemInputter* in; size_t first_pos = 0; int calls = 0;
+            void OnProcess(unsigned char*, size_t) override { if (calls++ == 0) first_pos = in->pos; }
+        };
+        MemInputter in(z, 23); MemOutputter out(24);
+        Ahead h; h.in = &in;
+        std::string threw;
+        int rc = -2;
+        try { rc = baidu::zling::Decode(&in, &out, &h); } catch (const std::exception& e) { threw = e.what(); }
+        printf("  ,\"decode_read_ahead_trait\": {\"rc\": %d, \"threw\": \"%s\", \"same_as_input\": %s, \"calls\": %d, \"inputter_pos_at_first_onprocess\": %zu}\n",
+               rc, threw.c_str(), (out.dst == x) ? "true" : "false", h.calls, h.first_pos);
+    }
     printf("}\n");
     return 0;
 }

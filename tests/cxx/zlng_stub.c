@@ -27,6 +27,8 @@ struct zlng_ctx {
     zo_dstream* ds;
     uint8_t* pending;
     size_t pending_len;
+    uint8_t* staged;                                     /* zlng_encode_finish_staged -> zlng_encode_copy_out */
+    size_t staged_len;
 };
 
 int zlng_device_count(void) { return 1; }
@@ -50,6 +52,7 @@ void zlng_destroy(zlng_ctx* c) {
     if (c->es) zo_stream_free(c->es);
     if (c->ds) zo_dstream_free(c->ds);
     free(c->pending);
+    free(c->staged);
     free(c);
 }
 
@@ -91,6 +94,26 @@ int zlng_encode_finish(zlng_ctx* c, uint8_t* out, size_t out_cap, size_t* out_le
     }
     free(c->pending); c->pending = NULL; c->pending_len = 0;
     *out_len = n;
+    return ZLNG_OK;
+}
+
+int zlng_encode_finish_staged(zlng_ctx* c, size_t out_cap, size_t* out_len, size_t* per_block_out_end) {
+    if (!c || !c->pending || !out_len) return ZLNG_E_ARG;
+    *out_len = 0;
+    const size_t bound = zlng_encode_bound(c->pending_len);
+    free(c->staged);
+    c->staged_len = 0;
+    c->staged = (uint8_t*)malloc(bound);
+    if (!c->staged) return ZLNG_E_NOMEM;
+    const int rc = zlng_encode_finish(c, c->staged, bound < out_cap ? bound : out_cap, &c->staged_len, per_block_out_end);
+    if (rc == ZLNG_OK) *out_len = c->staged_len;
+    return rc;
+}
+
+int zlng_encode_copy_out(zlng_ctx* c, uint8_t* out, size_t n) {
+    if (!c || !out || n != c->staged_len) return ZLNG_E_ARG;
+    if (n) memcpy(out, c->staged, n);
+    c->staged_len = 0;
     return ZLNG_OK;
 }
 

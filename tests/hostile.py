@@ -215,3 +215,159 @@ def mutants(oracle, seed, count, classes=CLASSES):
             continue
         bname, z, cap = bs[int(rng.integers(0, len(bs)))]
         yield "%s:%s" % (cls, bname), mutate(z, cls, rng, oracle), cap + (2 << 24)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Streams that reach the decoder's BIG structures ("what's weak" 1b): a ring that has wrapped (more than 4,096 token
+# starts in one context), a full 16 MiB block, match sources further back than the replay kernel's 64 KiB LDS window and copies that
+# straddle its wrap, generic-level multi-sub-block streams, crafted bodies of thousands of tokens, a block with more entries than a
+# block can hold.  `big_mutants` damages them with the same classes as above, weighted away from the classes the decoder's own
+# rejection rules decide (trunc, the header values >= 2^31): the share of mutants decided by a ZO_DEV_* rule is reported by the
+# tests and kept under 35 %.
+
+def M(ln, idx):
+    return (258 + ln - 4) | idx << 16
+
+
+def tok_bytes(tokens):
+    """Decoded length of a token list BEHIND the block's two raw opening entries (lengths are in the tokens, not in the data)."""
+    t = np.asarray(tokens, dtype=np.uint32) & 0xFFFF
+    return int(np.sum(np.where(t < 256, 1, np.where(t < 258, 2, t.astype(np.int64) - 258 + 4))))
+
+
+def frame_block(subs_tokens, oracle, opening=2):
+    """One block from a list of per-sub-block token lists; the first list starts with the block's two raw opening entries."""
+    parts, pos = [], 0
+    for k, t in enumerate(subs_tokens):
+        t = [int(v) for v in t]
+        if k == 0:
+            pos += opening + tok_bytes(t[opening:])
+        else:
+            pos += tok_bytes(t)
+        parts.append(_sub(t, pos, oracle))
+    return np.concatenate(parts + [np.array([0], np.uint8)]), pos
+
+
+def big_crafted(oracle, rng, kind=None):
+    """(name, stream, decoded size) -- VALID streams (every length lands on its encpos) built from thousands of tokens."""
+    k = int(rng.integers(0, 5)) if kind is None else kind
+    head = [65, 32]                                                   # opens in the blank's context
+    if k == 0:
+        # ring wrap: runs of rank-0 literals keep the context at the table's front symbol (the blank, src/tables/gen.py: mtfinit[0] = 32),
+        # so every token start lands in ONE bucket; matches name slots all over the ring -- before the 4,096th insert an index beyond
+        # the insert count names a slot nobody wrote (offset 0, a legal copy from the block's start), behind it every index is live
+        n = int(rng.integers(4300, 9000))
+        t = list(head)
+        for i in range(n):
+            r = rng.random()
+            if r < 0.90: t.append(0)
+            elif r < 0.94: t.append(int(rng.integers(2, 6)))          # another symbol: the context leaves the blank and comes back at once
+                                                                      # (rank 0 there is the blank too; rank 1 would move the blank off the front)
+            else: t.append(M(int(rng.integers(4, 40)), int(rng.choice([1, 2, 63, 64, 4094, 4095, int(rng.integers(1, 4096))]))))
+        z, size = frame_block([t], oracle)
+        return "big:ring-wrap", z, size
+    if k == 1:
+        # LDS window: a 2-byte period pushed across 64 KiB and 128 KiB by maximal matches, copies that start a few bytes in front of
+        # every 64 KiB boundary, then matches whose ring slot was written more than 128 KiB earlier (index = inserts since then)
+        t = list(head) + [7, 9, 11]
+        pos = 2 + 3
+        far_at = len(t)                                               # a token start early in the block, in the blank's bucket
+        while pos < 200000 + int(rng.integers(0, 70000)):
+            to_edge = 65536 - pos % 65536
+            if 4 <= to_edge - 3 <= 259 and rng.random() < 0.9:
+                ln = to_edge - int(rng.integers(1, 4)); t.append(M(max(4, ln), 1)); pos += max(4, ln)       # stops just short of the boundary
+                t.append(M(259, 1)); pos += 259                                                             # ... and the next copy straddles it
+            else:
+                t.append(M(259, 1)); pos += 259
+        inserts = len(t) - far_at                                     # every token since was a start in the same bucket (period of blanks)
+        for _ in range(20):
+            idx = min(4095, max(1, inserts - int(rng.integers(0, 4))))
+            t.append(M(int(rng.integers(4, 260)), idx)); inserts += 1
+        z, size = frame_block([t], oracle)
+        return "big:lds-window", z, size
+    if k == 2:
+        # three sub-blocks of random tokens: literals of every rank, word symbols, matches of every length and index
+        subs = []
+        for s in range(3):
+            n = int(rng.integers(20000, 60000))
+            kind_ = rng.random(n)
+            toks = np.where(kind_ < 0.55, rng.integers(0, 256, n),
+                            np.where(kind_ < 0.62, rng.integers(256, 258, n),
+                                     (258 + rng.integers(0, 256, n)) | (rng.integers(1, 4096, n) << 16))).astype(np.uint32)
+            subs.append(([65, 66] if s == 0 else []) + [int(v) for v in toks])
+        z, size = frame_block(subs, oracle)
+        if size > 16777216:
+            return big_crafted(oracle, rng, 0)
+        return "big:random-tokens-3-subblocks", z, size
+    if k == 3:
+        # two blocks: the literal tables carry over (rank r names another byte in block 2), the ring does not
+        b1, s1 = frame_block([list(head) + [int(v) for v in rng.integers(0, 50, 5000)] + [M(200, 5)] * 300], oracle)
+        b2, s2 = frame_block([[66, 67] + [int(v) for v in rng.integers(0, 50, 5000)] + [M(100, 4000), M(259, 1)] * 200], oracle)
+        return "big:two-blocks-carry", np.concatenate([b1, b2]), s1 + s2
+    # k == 4: more u16 entries than a block can hold: 64 sub-blocks of 262,144 blanks fill the 16 MiB exactly, a 65th sub-block
+    # crosses the limit.  With rlen <= 64 it is an ordinary sub-block whose lengths overshoot (lzdecode failed / or bad code1 with
+    # an empty table); beyond that the decoder rejects at its header (ZO_DEV_ENTRIES)
+    full = [list(head) + [0] * 262142] + [[0] * 262144 for _ in range(63)]
+    z, size = frame_block(full, oracle)
+    assert size == 16777216
+    extra = int(rng.choice([1, 64, 65, 100, 262144]))
+    tail = _sub([0] * extra, 16777216, oracle)
+    if rng.random() < 0.5:
+        tail[13: 13 + 257] = 0                                        # no code for any symbol: "bad code1" wherever the stream is read
+    return "big:too-many-entries(+%d)" % extra, np.concatenate([z[:-1], tail, np.array([0], np.uint8)]), 16777216
+
+
+_BIG = {}
+
+
+def big_bases(oracle):
+    """[(name, stream, output capacity)], built once per process: encoder-made streams at full size."""
+    if _BIG:
+        return _BIG["v"]
+    from oracle_py import textgen
+    out = []
+    x = textgen(16777216 + 700000, 3)                                  # a FULL block and a second one: rings wrapped thousands of times
+    out.append(("text_16m+.e0", oracle.encode(x, 0), x.size))
+    x = textgen(3000000, 5)                                            # generic level, several sub-blocks
+    out.append(("text_3m.e4", oracle.encode(x, 4), x.size))
+    # far sources: a rare context byte (0x01) in front of a phrase, 150-700 KB apart: its ring keeps the old starts, the matches
+    # reach back beyond the 64 KiB window and beyond 128 KiB; two blocks of it
+    rng = np.random.Generator(np.random.PCG64(99))
+    y = textgen(2 * 16777216 - 3000000, 7)
+    phrase = np.frombuffer(b"\x01the quick brown fox jumps over the lazy dog 0123456789 ABCDEFGHIJKLMNOPQRSTUVWXYZ", np.uint8)
+    p = 1000
+    while p + phrase.size < y.size:
+        y[p: p + phrase.size] = phrase
+        p += int(rng.integers(150000, 700000))
+    out.append(("far_sources_2blk.e0", oracle.encode(y, 0), y.size))
+    _BIG["v"] = out
+    return out
+
+
+BIG_CLASSES = ("bit", "byte", "span", "header", "flag", "table", "crafted", "bit", "span", "table", "crafted", "trunc")
+
+
+def big_mutants(oracle, seed, count):
+    """count x (name, bytes, output capacity): big crafted streams as they are (they must decode) and damaged, big encoder-made
+    streams damaged.  A pure function of the seed."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bs = big_bases(oracle)
+    for i in range(count):
+        cls = BIG_CLASSES[i % len(BIG_CLASSES)]
+        if cls == "crafted":
+            name, z, size = big_crafted(oracle, rng, i // len(BIG_CLASSES) % 5 if i < 5 * len(BIG_CLASSES) else None)
+            if rng.random() < 0.5 or name.startswith("big:too-many"):
+                yield name, z, size + (1 << 20)
+            else:
+                c2 = ("bit", "byte", "span", "header", "table")[int(rng.integers(0, 5))]
+                yield "%s:%s" % (c2, name), mutate(z, c2, rng, oracle), size + (2 << 24)
+            continue
+        bname, z, cap = bs[int(rng.integers(0, len(bs)))]
+        m = mutate(z, cls, rng, oracle)
+        if cls == "header" and rng.random() < 0.7:                     # mostly near-true values: the damage is met deep inside, not by a size rule
+            subs, _ = walk(z)
+            f, pay, e, r, o = subs[int(rng.integers(0, len(subs)))]
+            m = z.copy()
+            field = int(rng.integers(0, 2))
+            m[f + 1 + 4 * field: f + 5 + 4 * field] = _be((e, r)[field] + int(rng.choice([-2, -1, 1, 2, 259, -259])))
+        yield "%s:%s" % (cls, bname), m, cap + (2 << 24)

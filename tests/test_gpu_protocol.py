@@ -119,6 +119,18 @@ def test_decode_without_handler_batched_path(run):
     assert r["rc"] == 0 and r["same_as_input"] is True
 
 
+def test_per_call_traits_of_the_handler(run):
+    """libzling.h's two extension tags: EncodePlacement (this call over two contexts of device 0, the four longest rank chains on
+    host threads: same bytes) and DecodeReadAhead (this call may read ahead: the batched path, same output, and at the first
+    OnProcess the inputter already stands behind more than block 0 -- the whole 3-block stream fits the first 8 MiB chunk)."""
+    x, want, prefix, log = run
+    e = log["encode_placement"]
+    assert e["rc"] == 0 and e["threw"] == "" and e["same_bytes"] is True
+    d = log["decode_read_ahead_trait"]
+    assert d["rc"] == 0 and d["threw"] == "" and d["same_as_input"] is True and d["calls"] == 3
+    assert d["inputter_pos_at_first_onprocess"] > block_ends(want)[0]
+
+
 def _adler(a):
     import zlib
     return zlib.adler32(a.tobytes()) & 0xFFFFFFFF
