@@ -83,6 +83,8 @@ class RangeEncoder:
             s.set_host_rank_contexts(k)
 
     def parse(self, d_in, nbytes):
+        if getattr(self, "_broken", None) is not None:
+            raise RuntimeError("this RangeEncoder failed in an earlier step (a staggered parse could not be queued): close it") from self._broken
         off = 0
         self._lens = []
         jobs = []
@@ -143,13 +145,20 @@ class RangeEncoder:
         return int(self.stagger[0]), float(self.stagger[1])
 
     def finish(self, d_out, cap, d_state, level):
+        if getattr(self, "_broken", None) is not None:
+            raise RuntimeError("this RangeEncoder failed in an earlier step (a staggered parse could not be queued): close it") from self._broken
         segs, pos = [], 0
         for k, s in enumerate(self.streams):
             if self._queued:
                 self._queued[k].wait()                     # (the helper thread of a staggered schedule has queued this context's parse)
                 if getattr(self, "_late_error", None) is not None:
-                    err, self._late_error = self._late_error, None
-                    raise RuntimeError("a staggered parse could not be queued (context %d or later of this range)" % k) from err
+                    # Some contexts of this range hold a queued parse that will never be finished (the ones in front of k were
+                    # finished above and have moved the tables on): the range cannot be completed and the encoder's contexts are in
+                    # mixed states.  Wait for the helper, then refuse every further use -- close() is what is left.
+                    self._late.join()
+                    self._broken = self._late_error
+                    raise RuntimeError("a staggered parse could not be queued (context %d or later of this range); "
+                                       "this RangeEncoder is unusable now: close it" % k) from self._broken
             s.set_state_device(d_state, level)
             n = s.finish_device(d_out + pos, cap - pos)
             level = s.get_state_device(d_state)

@@ -253,6 +253,11 @@ def test_staggered_parse_that_fails_on_the_helper_thread_surfaces_in_finish_inst
     assert not t.is_alive(), "finish() hangs behind a parse that was never queued"
     assert isinstance(res.get("err"), RuntimeError) and "ZLNG_E_NOMEM" in str(res["err"].__cause__)
     assert ("finish", 0) in log and ("finish", 1) in log and ("finish", 2) not in log      # what was parsed still finishes in order
+    # contexts 0 and 1 have moved the tables on, context 3 holds a parse nobody will finish -- the encoder says so on
+    # every further use instead of queueing new parses onto streams in mixed states
+    for again in (lambda: enc.parse(1 << 40, 40 * BLOCK), lambda: enc.finish(1 << 41, 1 << 30, 1 << 42, 0)):
+        with pytest.raises(RuntimeError, match="close it"):
+            again()
     enc.close()
 
 
