@@ -225,6 +225,66 @@ def cpu_multistream(level, mib=128):
                       "encode in the reference, so this is a number about %d files, not about the metric's one stream" % (k, mib, k, level, k)}
 
 
+def gpu_multistream(k, x, level, local, want_sha, alone_ms):
+    """The GPU-side counterpart of cpu_baseline_multistream, an EXTRA and never `value`: K independent streams at once on ONE
+    device -- each with its own context (literal tables, pools, HIP stream), input and output buffers and host thread, all fed the
+    benchmark stream itself so that every stream's .zlng has the pinned SHA-256 (the device cannot know the inputs are equal: the
+    buffers are distinct).  One stream's parse keeps 60 of 256 CUs busy and its rank chain is one long wavefront among 256; this line
+    says what the rest of the chip is worth when there are K files instead of one."""
+    import threading
+    n = int(x.size)
+    nb = (n + BLOCK - 1) // BLOCK
+    cap = zl.encode_bound(n)
+    dev = torch.device("cuda", local)
+    hx = torch.from_numpy(x)
+    d_in, d_out, ctx = [], [], []
+    try:
+        for _ in range(k):
+            t = torch.empty(n + 512, dtype=torch.uint8, device=dev)
+            t[:n].copy_(hx); t[n:].zero_()
+            d_in.append(t)
+            d_out.append(torch.empty(cap, dtype=torch.uint8, device=dev))
+            ctx.append(zl.Stream(local, level, True, nb))
+        st0 = [c.get_state() for c in ctx]
+        lens, errs = [0] * k, []
+
+        def one(i):
+            try:
+                ctx[i].set_state(*st0[i])
+                lens[i] = ctx[i].encode_device(d_in[i].data_ptr(), n, d_out[i].data_ptr(), cap)
+            except Exception as e:                                   # noqa: BLE001 -- re-raised on the caller's thread below
+                errs.append(e)
+
+        def round_():
+            th = [threading.Thread(target=one, args=(i,)) for i in range(k)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize(dev)
+            if errs:
+                raise errs[0]
+        round_()                                                     # warm-up
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            round_()
+        dt = (time.perf_counter() - t0) / reps
+        stages = [dict(c.timings()) for c in ctx]
+        shas = [hashlib.sha256(d_out[i][: lens[i]].cpu().numpy().tobytes()).hexdigest() for i in range(k)]
+        return {"value": round(k * n / dt / 1e6, 2), "unit": "MB/s", "streams": k, "seconds_per_round": round(dt, 4),
+                "one_stream_alone_ms": round(alone_ms, 3), "speedup_over_one_stream": round((k * n / dt) / (n / (alone_ms * 1e-3)), 3) if alone_ms else None,
+                "stage_ms_per_stream": {"rolz_parse": [round(s.get("rolz_parse", 0.0), 1) for s in stages],
+                                        "mtf_chain": [round(s.get("mtf_chain", 0.0), 1) for s in stages]},
+                "parity": None if want_sha is None else bool(all(h == want_sha for h in shas)), "zlng_sha256_per_stream": shas,
+                "note": "EXTRA, not the metric and not `value`: %d independent streams of %d B at e%d at once on one GPU (own context, buffers and host "
+                        "thread each; every stream is fed the benchmark stream, so `parity` = every stream's SHA-256 is the pinned one); the counterpart "
+                        "of cpu_baseline_multistream -- a number about %d files, not about the metric's one stream" % (k, n, level, k)}
+    finally:
+        for c in ctx:
+            c.close()
+
+
 def rank_chain_line(x, level, hot_literals_gpu, mtf_ms):
     """ns per literal of the hottest context's serial rank chain (src/libzling_lz.cpp:112-117): on the GPU (stage time / that
     context's literals -- the stage is bounded by its longest chain) and on one host core (the reference's own
@@ -262,6 +322,7 @@ def main():
     ap.add_argument("--parity-live-max-mib", type=int, default=3072, help="a stream without pinned per-rank SHA-256 values is re-encoded whole by the CPU encoder on rank 0 for the parity column, up to this size")
     ap.add_argument("--no-multistream", action="store_true", help="skip cpu_baseline_multistream (K streams on K host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gpu-multistream", type=int, default=4, help="EXTRA (N = 1, one context): K independent streams at once on this one GPU, the counterpart of cpu_baseline_multistream (0 = skip)")
     ap.add_argument("--decode", action="store_true")
     ap.add_argument("--strong", action="store_true", help="N > 1: --size is the WHOLE stream, split over the ranks (strong scaling); default: --size per GPU (weak)")
     ap.add_argument("--no-realtext", action="store_true", help="skip the second, real-text workload (value_realtext)")
@@ -508,6 +569,10 @@ def main():
             optional(res, "alt_host_rank_chains", lambda: res.__setitem__("alt_host_rank_chains", alt_host_rank(args, local, nb, d_in, n, d_out, cap, d_state, d_state0, init_level, got)))
         if not args.no_cpu_baseline and not args.no_realtext and world == 1 and args.size == 1_000_000_000:
             optional(res, "realtext", lambda: res.update(realtext_workload(args, local)))
+        if args.gpu_multistream > 1 and not args.no_multistream and world == 1 and len(enc.parts) == 1 and nb <= 240:
+            pin = want[0][1] if (want and ranges_ok) else None         # the stream's pinned SHA-256 (only when this run matched it itself)
+            optional(res, "gpu_multistream", lambda: res.__setitem__("gpu_multistream", gpu_multistream(
+                args.gpu_multistream, x, args.level, local, pin, ms_per_step)))
         if alt_multi is not None:
             res["alt_host_rank_chains"] = alt_multi
         res["zlng_sha256_rank0"] = per_rank[0][1]
