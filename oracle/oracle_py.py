@@ -96,19 +96,27 @@ class Oracle:
         rc = self.lib.zo_decode_ex(_ptr(a) if a.size else None, a.size, _ptr(out), cap, C.byref(n), C.byref(fl))
         return rc, out[: n.value].copy(), int(fl.value)
 
-    def decode_stats(self, z, cap):
-        """(rc, dict): what the decode reached (zo_dstats, zlng_oracle.h)."""
+    def decode_stats(self, z, cap, lag=False):
+        """(rc, dict): what the decode reached (zo_dstats, zlng_oracle.h); lag=True also fills the replay-split model's fields."""
         class St(C.Structure):
             _fields_ = [("max_inserts_one_context", C.c_uint32), ("max_distance", C.c_uint32), ("matches", C.c_uint64),
                         ("matches_in_wrapped_ring", C.c_uint64), ("beyond_window", C.c_uint64), ("far_matches", C.c_uint64),
-                        ("dst_straddles_64k", C.c_uint64), ("src_straddles_64k", C.c_uint64), ("scratch", C.c_uint32 * 256)]
+                        ("dst_straddles_64k", C.c_uint64), ("src_straddles_64k", C.c_uint64), ("scratch", C.c_uint32 * 256),
+                        ("writer", C.c_void_p), ("lag_hist", C.c_uint64 * 24), ("tokens", C.c_uint64), ("literals", C.c_uint64),
+                        ("words", C.c_uint64), ("match_bytes", C.c_uint64)]
         a = np.ascontiguousarray(z)
         out = np.empty(max(cap, 1), dtype=np.uint8)
         n = C.c_size_t(0)
         st = St()
+        wr = np.zeros((1 << 24) + 1024, np.uint32) if lag else None
+        st.writer = wr.ctypes.data if lag else None
         self.lib.zo_decode_stats.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(St)]
         rc = self.lib.zo_decode_stats(_ptr(a), a.size, _ptr(out), cap, C.byref(n), C.byref(st))
-        return rc, {k: int(getattr(st, k)) for k, _ in St._fields_[:8]}
+        d = {k: int(getattr(st, k)) for k, _ in St._fields_[:8]}
+        if lag:
+            d.update(lag_hist=[int(v) for v in st.lag_hist], tokens=int(st.tokens), literals=int(st.literals), words=int(st.words),
+                     match_bytes=int(st.match_bytes))
+        return rc, d
 
     # ---- stage API -------------------------------------------------------------------
     def parse_block(self, block, level=0, apply_mtf=False, stream=None):

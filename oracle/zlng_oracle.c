@@ -642,14 +642,17 @@ static int decode_one_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* 
                     uint8_t c = t[v], nx = g_mtfnext[v];
                     t[v] = t[nx]; t[nx] = c;
                     blk[opos++] = c; ti++;
+                    if (g_stats) { g_stats->tokens++; g_stats->literals++; if (g_stats->writer) g_stats->writer[opos - 1] = (uint32_t)g_stats->tokens; }
                     mru[blk[opos - 3]][1] = mru[blk[opos - 3]][0];
                     mru[blk[opos - 3]][0] = (uint16_t)(blk[opos - 2] << 8 | blk[opos - 1]);
                 } else if (v == 256) {
                     uint16_t w = mru[blk[opos - 1]][0];
                     blk[opos++] = (uint8_t)(w >> 8); blk[opos++] = (uint8_t)w; ti++;
+                    if (g_stats) { g_stats->tokens++; g_stats->words++; if (g_stats->writer) g_stats->writer[opos - 2] = g_stats->writer[opos - 1] = (uint32_t)g_stats->tokens; }
                 } else if (v == 257) {
                     uint16_t w = mru[blk[opos - 1]][1];
                     blk[opos++] = (uint8_t)(w >> 8); blk[opos++] = (uint8_t)w; ti++;
+                    if (g_stats) { g_stats->tokens++; g_stats->words++; if (g_stats->writer) g_stats->writer[opos - 2] = g_stats->writer[opos - 1] = (uint32_t)g_stats->tokens; }
                     mru[blk[opos - 3]][1] = mru[blk[opos - 3]][0];
                     mru[blk[opos - 3]][0] = (uint16_t)(blk[opos - 2] << 8 | blk[opos - 1]);
                 } else {
@@ -667,6 +670,20 @@ static int decode_one_block(zo_dstream* d, const uint8_t* in, size_t n, size_t* 
                         if (((uint32_t)opos >> 16) != (((uint32_t)opos + (uint32_t)mlen - 1) >> 16)) g_stats->dst_straddles_64k++;
                         if ((src >> 16) != ((src + (uint32_t)mlen - 1) >> 16)) g_stats->src_straddles_64k++;
                         if (g_stats->inserts_scratch[blk[opos - 1]] > ZO_RING && idx > 0) g_stats->matches_in_wrapped_ring++;
+                    }
+                    if (g_stats) {
+                        g_stats->tokens++; g_stats->match_bytes += (uint64_t)mlen;
+                        if (g_stats->writer && opos >= 2) {
+                            uint32_t* wr = g_stats->writer;
+                            /* the copy's last source byte; for a self-overlapping copy it is a byte this very copy writes: no wait */
+                            const uint32_t last = src + (uint32_t)mlen - 1;
+                            if (last < (uint32_t)opos) {
+                                uint64_t lag = g_stats->tokens - (src + (uint32_t)mlen - 1 < 2 ? 0 : wr[last]);
+                                int k = 0; while (lag > 1 && k < 23) { lag >>= 1; k++; }
+                                g_stats->lag_hist[k]++;
+                            } else g_stats->lag_hist[23]++;               /* [23]: self-overlap */
+                            for (int k = 0; k < mlen; k++) wr[opos + k] = (uint32_t)g_stats->tokens;
+                        }
                     }
                     for (int k = 0; k < mlen; k++) blk[opos + k] = blk[src + k];   /* :91-104 forward copy */
                     opos += mlen;
@@ -725,7 +742,9 @@ done:
 }
 
 int zo_decode_stats(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, zo_dstats* st) {
+    uint32_t* writer = st->writer;
     memset(st, 0, sizeof *st);
+    st->writer = writer;
     g_stats = st;
     const int rc = zo_decode_ex(in, n, out, cap, out_len, NULL);
     g_stats = NULL;
