@@ -225,7 +225,7 @@ def cpu_multistream(level, mib=128):
                       "encode in the reference, so this is a number about %d files, not about the metric's one stream" % (k, mib, k, level, k)}
 
 
-def gpu_multistream(k, x, level, local, want_sha, alone_ms):
+def gpu_multistream(k, x, level, local, want_sha, alone_ms, device=None):
     """The GPU-side counterpart of cpu_baseline_multistream, an EXTRA and never `value`: K independent streams at once on ONE
     device -- each with its own context (literal tables, pools, HIP stream), input and output buffers and host thread, all fed the
     benchmark stream itself so that every stream's .zlng has the pinned SHA-256 (the device cannot know the inputs are equal: the
@@ -235,7 +235,7 @@ def gpu_multistream(k, x, level, local, want_sha, alone_ms):
     n = int(x.size)
     nb = (n + BLOCK - 1) // BLOCK
     cap = zl.encode_bound(n)
-    dev = torch.device("cuda", local)
+    dev = device or torch.device("cuda", local)                  # (device: tests/test_bench_host.py drives the host logic on the CPU)
     hx = torch.from_numpy(x)
     d_in, d_out, ctx = [], [], []
     try:
@@ -261,7 +261,8 @@ def gpu_multistream(k, x, level, local, want_sha, alone_ms):
                 t.start()
             for t in th:
                 t.join()
-            torch.cuda.synchronize(dev)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
             if errs:
                 raise errs[0]
         round_()                                                     # warm-up
@@ -283,6 +284,19 @@ def gpu_multistream(k, x, level, local, want_sha, alone_ms):
     finally:
         for c in ctx:
             c.close()
+
+
+def gpu_multistream_isolated(k, size, level, local, want_sha, alone_ms):
+    """gpu_multistream in a process of its own with a time limit: K host threads driving K contexts at once is the one shape of
+    use the headline run does not exercise, and whatever it does -- an abort inside the runtime, a hang -- must not cost the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpu-multistream-child", str(k), "--size", str(size), "--level", str(level),
+           "--child-device", str(local), "--child-alone-ms", repr(float(alone_ms)), "--child-want-sha", want_sha or "-"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("child exited %d: %s" % (r.returncode, r.stderr[-400:]))
+    return json.loads(lines[-1])
 
 
 def rank_chain_line(x, level, hot_literals_gpu, mtf_ms):
@@ -322,6 +336,10 @@ def main():
     ap.add_argument("--parity-live-max-mib", type=int, default=3072, help="a stream without pinned per-rank SHA-256 values is re-encoded whole by the CPU encoder on rank 0 for the parity column, up to this size")
     ap.add_argument("--no-multistream", action="store_true", help="skip cpu_baseline_multistream (K streams on K host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gpu-multistream-child", type=int, default=0, help=argparse.SUPPRESS)      # internal: the isolated leg of gpu_multistream
+    ap.add_argument("--child-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--child-alone-ms", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--child-want-sha", default="-", help=argparse.SUPPRESS)
     ap.add_argument("--gpu-multistream", type=int, default=4, help="EXTRA (N = 1, one context): K independent streams at once on this one GPU, the counterpart of cpu_baseline_multistream (0 = skip)")
     ap.add_argument("--decode", action="store_true")
     ap.add_argument("--strong", action="store_true", help="N > 1: --size is the WHOLE stream, split over the ranks (strong scaling); default: --size per GPU (weak)")
@@ -331,6 +349,13 @@ def main():
     ap.add_argument("--parts", default="", help="explicit block counts of the contexts of this rank's range, e.g. 64,128,128,128,64 (default: even parts of --ctx-blocks)")
     ap.add_argument("--wg-waves", type=int, default=int(os.environ.get("ZLNG_WG_WAVES", "4")), help="wavefronts per block of the parser (recorded in roofline.waves_per_block)")
     args = ap.parse_args()
+
+    if args.gpu_multistream_child:                                   # the isolated leg of gpu_multistream (see gpu_multistream_isolated)
+        torch.cuda.set_device(args.child_device)
+        x, source = load_input(args.size, 0)
+        print(json.dumps(gpu_multistream(args.gpu_multistream_child, x, args.level, args.child_device,
+                                         None if args.child_want_sha == "-" else args.child_want_sha, args.child_alone_ms)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -571,8 +596,8 @@ def main():
             optional(res, "realtext", lambda: res.update(realtext_workload(args, local)))
         if args.gpu_multistream > 1 and not args.no_multistream and world == 1 and len(enc.parts) == 1 and nb <= 240:
             pin = want[0][1] if (want and ranges_ok) else None         # the stream's pinned SHA-256 (only when this run matched it itself)
-            optional(res, "gpu_multistream", lambda: res.__setitem__("gpu_multistream", gpu_multistream(
-                args.gpu_multistream, x, args.level, local, pin, ms_per_step)))
+            optional(res, "gpu_multistream", lambda: res.__setitem__("gpu_multistream", gpu_multistream_isolated(
+                args.gpu_multistream, args.size, args.level, local, pin, ms_per_step)))
         if alt_multi is not None:
             res["alt_host_rank_chains"] = alt_multi
         res["zlng_sha256_rank0"] = per_rank[0][1]

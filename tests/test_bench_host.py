@@ -173,3 +173,51 @@ print("ok")
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_gpu_multistream_host_logic_with_a_stand_in_stream(oracle, monkeypatch):
+    """bench.gpu_multistream (K contexts driven by K host threads, per-stream SHA-256 against the pin) has never met a GPU when
+    this was written; its host logic -- buffers, threads, state reset, timing fields, the parity column -- runs here against a
+    stand-in for zl.Stream that encodes with the checker into the buffer it is handed.  The kernels are not involved."""
+    import ctypes
+    import hashlib
+
+    import numpy as np
+    import torch
+
+    class FakeStream:
+        made = []
+
+        def __init__(self, device, level, is_encode, nblocks):
+            self.level, self.state, self.closed = level, (np.zeros(65536, np.uint8), 0), False
+            FakeStream.made.append(self)
+
+        def get_state(self):
+            return self.state
+
+        def set_state(self, mtf, level):
+            self.state = (mtf, level)
+
+        def encode_device(self, d_in, n, d_out, cap):
+            x = np.frombuffer((ctypes.c_uint8 * n).from_address(d_in), np.uint8)
+            z = oracle.encode(x, self.level)
+            assert z.size <= cap
+            ctypes.memmove(d_out, z.ctypes.data, z.size)
+            return int(z.size)
+
+        def timings(self):
+            return [("rolz_parse", 1.0), ("mtf_chain", 2.0)]
+
+        def close(self):
+            self.closed = True
+    monkeypatch.setattr(bench.zl, "Stream", FakeStream)
+    from libzling_amd.textgen import textgen
+    x = textgen(300_000, 1)
+    want = hashlib.sha256(oracle.encode(x, 0).tobytes()).hexdigest()
+    g = bench.gpu_multistream(3, x, 0, 0, want, 10.0, device=torch.device("cpu"))
+    assert g["streams"] == 3 and g["parity"] is True and g["zlng_sha256_per_stream"] == [want] * 3 and g["value"] > 0
+    assert g["stage_ms_per_stream"] == {"rolz_parse": [1.0] * 3, "mtf_chain": [2.0] * 3} and g["speedup_over_one_stream"] > 0
+    assert len(FakeStream.made) == 3 and all(s.closed for s in FakeStream.made)
+    g = bench.gpu_multistream(2, x, 0, 0, "0" * 64, 10.0, device=torch.device("cpu"))
+    assert g["parity"] is False
+    assert bench.gpu_multistream(2, x, 0, 0, None, 0.0, device=torch.device("cpu"))["parity"] is None
