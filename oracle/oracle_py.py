@@ -96,6 +96,33 @@ class Oracle:
         rc = self.lib.zo_decode_ex(_ptr(a) if a.size else None, a.size, _ptr(out), cap, C.byref(n), C.byref(fl))
         return rc, out[: n.value].copy(), int(fl.value)
 
+    def decode_blockwise(self, z, cap, state=None):
+        """The block-at-a-time decoder (zo_dstream_*, what tests/cxx/zlng_stub.c is built on): (rc, bytes of the good blocks in front
+        of the first error, blocks decoded, final tables).  `state`: 65,536 table bytes to start from (default: a fresh decoder)."""
+        L = self.lib
+        L.zo_dstream_new.restype = C.c_void_p
+        L.zo_dstream_free.argtypes = [C.c_void_p]
+        L.zo_dstream_get_mtf.argtypes = [C.c_void_p, _u8p]
+        L.zo_dstream_set_mtf.argtypes = [C.c_void_p, _u8p]
+        L.zo_dstream_decode_block.argtypes = [C.c_void_p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+        a = np.ascontiguousarray(z)
+        d = L.zo_dstream_new()
+        if state is not None:
+            L.zo_dstream_set_mtf(d, _ptr(np.ascontiguousarray(state)))
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        ip, op, nblk, rc = C.c_size_t(0), 0, 0, 0
+        while ip.value < a.size:
+            n = C.c_size_t(0)
+            rc = L.zo_dstream_decode_block(d, _ptr(a), a.size, C.byref(ip), _ptr(out[op:]) if op < out.size else _ptr(out), cap - op, C.byref(n), None)
+            if rc != 0:
+                break
+            op += n.value
+            nblk += 1
+        mtf = np.empty(65536, np.uint8)
+        L.zo_dstream_get_mtf(d, _ptr(mtf))
+        L.zo_dstream_free(d)
+        return rc, out[:op].copy(), nblk, mtf
+
     def decode_stats(self, z, cap, lag=False):
         """(rc, dict): what the decode reached (zo_dstats, zlng_oracle.h); lag=True also fills the replay-split model's fields."""
         class St(C.Structure):

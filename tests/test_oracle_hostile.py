@@ -218,3 +218,29 @@ def test_oracle_equals_the_reference_on_big_hostile_streams(oracle):
     assert dev / n < 0.35, (dev, n)
     assert stats[0] >= 20 and stats[-7] >= 40 and stats[-4] + stats[-5] >= 5
     print("big hostile: %d mutants, %d by a deviation rule (%.0f %%), verdicts %s" % (n, dev, 100.0 * dev / n, dict(stats)))
+
+
+def test_blockwise_decoder_equals_the_whole_stream_decoder_and_rolls_back(oracle):
+    """zo_dstream_decode_block (the block-at-a-time form with carried tables that the C-ABI stand-in of the CPU suite is built on,
+    tests/cxx/zlng_stub.c) against zo_decode_ex: same verdict, same bytes in front of the error, on valid multi-block streams and on
+    hostile mutants; and an error leaves the tables as the last good block left them -- the same good block decodes the same way after
+    a failed one as before it."""
+    n_err = 0
+    for name, m, cap in hostile.mutants(oracle, 606, 700):
+        rc, y, _flags = oracle.decode_ex(m, cap)
+        rc2, y2, nblk, mtf = oracle.decode_blockwise(m, cap)
+        assert rc2 == rc and np.array_equal(y2, y), name
+        n_err += rc != 0
+    assert n_err > 200
+    import corpus
+    x = corpus.get("carry_2blk")
+    z = oracle.encode(x, 0)
+    subs, ends = hostile.walk(z)
+    b1 = z[: ends[0] + 1]                                              # the first block alone
+    rc, y1, nblk, t1 = oracle.decode_blockwise(b1, x.size)
+    assert rc == 0 and nblk == 1
+    bad = z[ends[0] + 1:].copy(); bad[13: 13 + 257] = 0                 # the second block with an empty length table
+    rc, _y, nblk, t_after_bad = oracle.decode_blockwise(bad, x.size, state=t1)
+    assert rc == -4 and nblk == 0 and np.array_equal(t_after_bad, t1)   # bad code1; tables untouched
+    rc, y2, nblk, _t = oracle.decode_blockwise(z[ends[0] + 1:], x.size, state=t_after_bad)
+    assert rc == 0 and np.array_equal(np.concatenate([y1, y2]), x)      # ... and the real second block still decodes on them
