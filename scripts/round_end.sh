@@ -7,11 +7,14 @@
 #      over gloo -- RCCL refuses two ranks on one device), every line with parity / roofline / cpu_baseline
 #   4. config 4's per-GPU share (8 GiB at e4), one 4 GiB stream at e0 (longer than a context), K = 2 / 8 streams at once on the GPU, the decode line
 #   5. scripts/ring_fix_ab.sh ring-only: the GPU suite and the e1/e4 lines with ZLNG_RING_FIX=1 against the same without it
+#   scripts/round_end.sh r06_a quick      -> steps 1 and 2 only (~20 min): the suite and the profile set, for a GPU slot that opens late
 set -u
 TAG=${1:-r05_x}
+QUICK=${2:-}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 (time timeout 2400 python -m pytest tests -m gpu -x -q) > $OUT/${TAG}_gpu_tests.txt 2>&1; tail -3 $OUT/${TAG}_gpu_tests.txt
 bash scripts/profile_round.sh $TAG
+if [ "$QUICK" = quick ]; then exit 0; fi
 export MASTER_ADDR=127.0.0.1
 ZLNG_BENCH_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
     bench.py --gpus 2 --steps 2 --warmup 1 --size 402653184 --no-multistream 2> $OUT/${TAG}_two_ranks.err | grep '^{' > $OUT/${TAG}_two_ranks_one_device.json
