@@ -137,11 +137,12 @@ def test_shim_spreads_one_stream_over_devices(oracle, level, devices, batch):
 
 
 def test_batched_decode_moves_to_the_full_size_context_and_keeps_the_tables(tmp_path, oracle):
-    """Decode() without handler-side reads (no handler, or ZLNG_DECODE_READAHEAD=1) starts on a 4-block context and rebuilds a
-    full-size one once the stream has produced 4 blocks, carrying the literal tables over (zlng_get_state / zlng_set_state).
-    Seven blocks of compressible data -- every one arrives inside the first 8 MiB chunk -- cross that rebuild; the literals behind
-    it only decode if the tables came along (src/libzling_lz.cpp:378-386: the decoder's Reset keeps m_mtf)."""
-    n = 6 * corpus.BLOCK + 300_000
+    """Decode() without handler-side reads (no handler, a DecodeReadAhead handler, or ZLNG_DECODE_READAHEAD=1) starts on a 4-block
+    context and rebuilds a larger one once the stream has produced 4 blocks (four times the blocks, but no more than are left once the
+    input has ended), carrying the literal tables over (zlng_get_state / zlng_set_state).  Ten blocks of compressible data -- every
+    one arrives inside the first 8 MiB chunk, so six are left behind the first call: a 6-block context -- cross that rebuild; the
+    literals behind it only decode if the tables came along (src/libzling_lz.cpp:378-386: the decoder's Reset keeps m_mtf)."""
+    n = 9 * corpus.BLOCK + 300_000
     unit = corpus.get("text_64k")
     x = np.concatenate([unit] * (n // unit.size + 1))[:n].copy()
     x[5 * corpus.BLOCK + 1000: 5 * corpus.BLOCK + 201000] = corpus.get("text_700k")[:200000]     # fresh literals behind the rebuild
