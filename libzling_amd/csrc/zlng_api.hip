@@ -197,7 +197,7 @@ void run_front(zlng_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t nb, uin
     static const int min_restart = getenv("ZLNG_MIN_RESTART") ? atoi(getenv("ZLNG_MIN_RESTART")) : 12;
     static const int prefix_pct = getenv("ZLNG_PREFIX_PCT") ? atoi(getenv("ZLNG_PREFIX_PCT")) : 0;      // measured within +-1 % of "always iterate" on every workload: off
     static const int ring_fix = getenv("ZLNG_RING_FIX") ? atoi(getenv("ZLNG_RING_FIX")) : 0;           // round 5: exact in the CPU model, not yet measured on a GPU: off
-    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, prefix_pct, ring_fix, c->tok_cap, blk0, overflow_flag(c)};
+    ParseArgs pa{d_in, in_len, c->d_dict, c->d_tok, c->d_cuts, c->d_nsub, c->d_ntok, c->d_sched, c->d_dbg, min_restart, prefix_pct, c->tok_cap, blk0, overflow_flag(c), ring_fix};
     static const int wg_waves = [] {
         const int v = getenv("ZLNG_WG_WAVES") ? atoi(getenv("ZLNG_WG_WAVES")) : 4;
         if (v != 2 && v != 4 && v != 8) fprintf(stderr, "zlng: ZLNG_WG_WAVES=%d is not 2, 4 or 8: using %d\n", v, v <= 2 ? 2 : (v <= 4 ? 4 : 8));

@@ -18,11 +18,13 @@ struct ParseArgs {
     int            min_restart; // levels 1-4: < 0 replays every hard token by the serial code instead of starting the next round at it (ZLNG_MIN_RESTART)
     int            prefix_pct;  // after a round's first iteration: commit the tokens in front of the first changed one instead of iterating when they
                                 // are at least this share (%) of the round's tokens (0: always iterate, the default; ZLNG_PREFIX_PCT)
-    int            ring_fix;    // levels 1-4: a chain node taken over by a token of the round ends the walk in front of it instead of making the token hard (ZLNG_RING_FIX)
     uint32_t       tok_cap;     // token words reserved per block
     uint32_t       blk0;        // first block of this launch (a level-schedule repair re-parses a tail of the range)
     uint32_t*      overflow;    // 1: a block ran out of token words (its output is then incomplete; the host grows the pools once and repeats);
                                 // 2: a "cannot happen" guard of the parser fired (the host fails the call, ZLNG_E_DEVICE)
+    int            ring_fix;    // levels 1-4: a chain node taken over by a token of the round ends the walk in front of it instead of making the token hard (ZLNG_RING_FIX).
+                                // LAST on purpose: the fields in front keep the kernarg offsets of the kernels that last ran on a GPU, so the level-0
+                                // instantiations (which never read this) stay instruction-identical to them (scripts/isa_diff.py)
 };
 // the workgroup-wide parser (rolz_wg.hip): nw wavefronts per block, window of 64 nw positions
 void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks, hipStream_t s, bool all_level0, int nw, bool wide, bool hot);   // wide: slot plane form at level 0; hot: one bucket mirrored in LDS

@@ -121,3 +121,35 @@ def test_the_hazard_scanner_sees_what_it_should():
 def test_no_valu_reads_an_sgpr_a_valu_wrote_less_than_two_wait_states_ago(tmp_path, name):
     bad = valu_sgpr_hazards(isa_of(tmp_path, name))
     assert not bad, (len(bad), bad[:8])
+
+
+# ---- the kernels at HEAD against the kernels that last ran on a GPU -------------------------------------------------------------
+# tests/golden/kernel_isa_last_gpu_run.json (scripts/isa_diff.py --pin b703640): the instruction stream of every kernel of b703640, the
+# last commit before the GPU pool closed to this repository in the middle of round 5 (its kernel sources are those of d0b3819, 06:31 that
+# day; the GPU suite -- 134 passed, profiles/r05_d_gpu_tests.txt -- the hostile soak and the config-4 runs of that morning were taken on
+# them or on the working tree of the minutes before; everything the round-5 review lists as "never executed on a GPU" came after).  What
+# CAN be shown without a GPU is that the machine code of every kernel on the default paths -- encode at level 0, both rank kernels, the
+# Huffman kernels, all three decode kernels -- is still that code, instruction for instruction, and which kernels are not: the
+# generic-level parser, which carries the ring rule's code (off by default, never run).  ParseArgs::ring_fix sits LAST in the argument
+# block for this reason: the level-0 instantiations never read it, and with the other fields' offsets unchanged they compile to the
+# very same instructions (only .amdhsa_kernarg_size differs, which the comparison leaves out).
+GENERIC_LEVEL_PARSER = {"rolz_wg.hip:k_rolz_parse_wg<%d, false, %s, false, false>" % (nw, p) for nw in (2, 4, 8) for p in ("false", "true")}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_kernels_are_instruction_identical_to_the_last_gpu_run_except_the_generic_level_parser():
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_diff
+    pins = json.load(open(os.path.join(ROOT, "tests", "golden", "kernel_isa_last_gpu_run.json")))
+    if pins["hipcc"] != isa_diff.hipcc_version():
+        pytest.skip("another hipcc than the one the pins were taken with: %s" % isa_diff.hipcc_version())
+    here = {}
+    for name in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
+        for k, v in (isa_diff.kernels(CSRC, name) or {}).items():
+            here["%s:%s" % (name, k)] = isa_diff.stream_hash(v)
+    assert set(here) == set(pins["kernels"]), sorted(set(here) ^ set(pins["kernels"]))
+    differ = {k for k in here if here[k] != pins["kernels"][k]["sha"]}
+    assert GENERIC_LEVEL_PARSER <= set(here)
+    assert differ <= GENERIC_LEVEL_PARSER, sorted(differ - GENERIC_LEVEL_PARSER)
