@@ -184,8 +184,9 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *   ZLNG_PREFIX_PCT=<0..100>      parser: after a round's first iteration, commit the tokens in front of the first changed one instead of
  *                                 iterating when they are at least this share of the round's tokens (0 = always iterate, the default: measured within +-1 % on every workload)
  *   ZLNG_RING_FIX=1               parser, levels 1-4: a chain node whose ring slot a token of the same round has taken over ends the walk in front
- *                                 of it (exact: the reference's chain-end test stops there) instead of making the token a serially replayed one;
- *                                 exact in the CPU model at every level (scripts/experiments/wg_parser_model.c), not yet measured on a GPU: off
+ *                                 of it (exact: the reference's chain-end test stops there) instead of making the token a serially replayed one.
+ *                                 Selects separate kernel instantiations (rolz_wg.hip kRingRule): the default ones hold none of its code.  Exact in the
+ *                                 CPU model at every level (scripts/experiments/wg_parser_model.c), never run on a GPU: off
  *   ZLNG_CHAIN_PRIO=0             k_mtf_chain without its raised issue priority (s_setprio 3; on by default: the rank chain is one dependent
  *                                 chain per wavefront, and beside another context's parser waves on its SIMD it should win every arbitration)
  *   ZLNG_DEBUG_PACK_LDS=<bytes>   extra dynamic LDS for the bit packer's launch (occupancy experiments)

@@ -217,9 +217,13 @@ __device__ __forceinline__ bool ev_state(u64 M, u64 COND, uint32_t m0, const uin
 // One workgroup per block.  NW wavefronts; lane g = 64 * wavefront + lane stands for position P + g.  The fixed-point iteration
 // works on the TOKENS of S, numbered by rank (their order in S; at most 64 per round): every relation between tokens -- same hash
 // slot, same bucket, same MRU key -- is one 64-bit rank mask in LDS, rebuilt per iteration by the tokens of S themselves.
-template <int NW, bool kAllL0, bool kProf, bool kWide, bool kHot = false>
+// kRingRule: the ring rule of levels 1-4 (ZLNG_RING_FIX=1; see E below) as an instantiation of its own -- built in round 5, exact in the CPU
+// model, never run on a GPU.  With kRingRule = false none of its code is in the kernel: the default instantiations are, instruction for
+// instruction, the kernels that last ran on one (scripts/isa_diff.py, tests/test_isa_hygiene.py).
+template <int NW, bool kAllL0, bool kProf, bool kWide, bool kHot = false, bool kRingRule = false>
 __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
     constexpr int NL = 64 * NW;
+    static_assert(!kRingRule || !kAllL0, "the ring rule belongs to the generic-level walk");
     static_assert(!kHot || (kWide && kAllL0), "the LDS bucket mirrors the wide layout of a level-0 context");
     __shared__ u64 hot_lds[kHot ? kBktBytes / 8 : 1];     // kHot: write-through mirror of one bucket (57,344 B)
     __shared__ uint32_t hot_hist[kHot ? 256 : 1];
@@ -426,8 +430,8 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 S1.sp = kMatchMin - 1; S1.node0 = 65535; S1.head0 = 0; S1.dmin = kRing - 1;
                 S1.lkix1 = S1.lkix2 = S1.lctx1 = S1.lctx2 = 0; S1.lz1 = S1.lz2 = false; S1.ld1 = S1.ld2 = kRing - 1; S1.ov0 = 0;
                 S1.pre1 = S1.pre2 = kMatchMin - 1; S1.vpos1 = S1.vpos2 = 0;
-                S1.d0g = kRing - 1; S1.tail0 = S1.tail1 = S1.tail2 = S1.ntail = 0;
-                if (canm) speculate_from(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk, hd0, hd1, hd2, a.ring_fix != 0);
+                if constexpr (kRingRule) { S1.d0g = kRing - 1; S1.tail0 = S1.tail1 = S1.tail2 = S1.ntail = 0; }
+                if (canm) speculate_from(S1, dict, buf, heads[ctx], heads[lctx1], heads[lctx2], 0u, pos, cfg, qtext, ctx, hc, chk, hd0, hd1, hd2, kRingRule);
                 W.len = S1.sp & kSpLenMask; W.node = (S1.sp >> kSpNodeShift) & (kRing - 1);
                 W.node0 = S1.node0; W.ov0 = S1.ov0; W.dmin = S1.dmin; W.d0 = W.d1 = S1.dmin;
                 W.has0 = S1.node0 != 65535u; W.has1 = false; W.len0 = 0;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                 W.lkey2 = lkey2;
                 W.ld1 = S1.ld1; W.ld2 = S1.ld2; W.lsrc1 = 0;
                 W.pre1 = S1.pre1; W.pre2 = S1.pre2; W.vpos1 = S1.vpos1; W.vpos2 = S1.vpos2;
-                W.d0g = S1.d0g; W.tail0 = S1.tail0; W.tail1 = S1.tail1; W.tail2 = S1.tail2; W.ntail = S1.ntail;
+                if constexpr (kRingRule) { W.d0g = S1.d0g; W.tail0 = S1.tail0; W.tail1 = S1.tail1; W.tail2 = S1.tail2; W.ntail = S1.ntail; }
             }
             const uint32_t head0 = heads[ctx];
             const uint32_t m0c = mru[ctx], m0e = mru[ek];           // MRU slots of my check key / my event key at the start of the round
@@ -687,18 +691,23 @@ __global__ __launch_bounds__(64 * NW) void k_rolz_parse_wg(ParseArgs a) {
                     // there and its chain-end test stops (src/libzling_lz.cpp:265) -- so the match is the best over the nodes before
                     // it, which phase 1 recorded for the walk's tail.  Node 0 taken over, a token of the round in my hash slot as well,
                     // or a tail longer than the record: still hard.  (A slot that was only read for the chain-end test changes nothing.)
-                    const bool ringhit = W.dmin <= k;
-                    bool cut = false;
-                    uint32_t cutpre = W.len | W.node << kSpNodeShift;
-                    if (a.ring_fix != 0 && ecan && ringhit && !has_a1 && W.d0g > k) {
-                        const bool v0 = W.ntail > 0u && (W.tail0 & 63u) <= k, v1 = W.ntail > 1u && (W.tail1 & 63u) <= k, v2 = W.ntail > 2u && (W.tail2 & 63u) <= k;
-                        if (v0) { cut = true; cutpre = W.tail0 >> 6; }
-                        else if (v1) { cut = true; cutpre = W.tail1 >> 6; }
-                        else if (v2) { cut = true; cutpre = W.tail2 >> 6; }
-                        else cut = W.ntail <= 3u;
+                    if constexpr (kRingRule) {
+                        const bool ringhit = W.dmin <= k;
+                        bool cut = false;
+                        uint32_t cutpre = W.len | W.node << kSpNodeShift;
+                        if (ecan && ringhit && !has_a1 && W.d0g > k) {
+                            const bool v0 = W.ntail > 0u && (W.tail0 & 63u) <= k, v1 = W.ntail > 1u && (W.tail1 & 63u) <= k, v2 = W.ntail > 2u && (W.tail2 & 63u) <= k;
+                            if (v0) { cut = true; cutpre = W.tail0 >> 6; }
+                            else if (v1) { cut = true; cutpre = W.tail1 >> 6; }
+                            else if (v2) { cut = true; cutpre = W.tail2 >> 6; }
+                            else cut = W.ntail <= 3u;
+                        }
+                        hard = ecan && ((ringhit && !cut) || has_a3);
+                        ml = cutpre & kSpLenMask; mn = (cutpre >> kSpNodeShift) & (kRing - 1);
+                    } else {
+                        hard = ecan && (W.dmin <= k || has_a3);
+                        ml = W.len; mn = W.node;
                     }
-                    hard = ecan && ((ringhit && !cut) || has_a3);
-                    ml = cutpre & kSpLenMask; mn = (cutpre >> kSpNodeShift) & (kRing - 1);
                     const bool fixl = ecan && !hard && has_a1;
                     if (__any(fixl)) {
                         const uint32_t k1 = t_key[a1], k2 = t_key[a2], la1 = t_lane[a1], la2 = t_lane[a2];
@@ -954,6 +963,8 @@ void launch_rolz_parse_wg(const ParseArgs& a, uint32_t nblocks_all, hipStream_t 
         else if (all_level0 && wide) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, true, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);        \
         else if (all_level0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, false, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);     \
         else if (all_level0) hipLaunchKernelGGL((k_rolz_parse_wg<NW, true, true, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);               \
+        else if (a.ring_fix != 0 && !prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, false, false, false, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);  \
+        else if (a.ring_fix != 0) hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, true, false, false, true>), dim3(nblocks), dim3(64 * NW), 0, s, a);  \
         else if (!prof) hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, false, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);                  \
         else hipLaunchKernelGGL((k_rolz_parse_wg<NW, false, true, false>), dim3(nblocks), dim3(64 * NW), 0, s, a);                              \
     } while (0)

@@ -32,6 +32,8 @@ def kernels(csrc, name):
         if m:
             cur = subprocess.run(["c++filt", m.group(1)], stdout=subprocess.PIPE, text=True).stdout.strip()
             cur = re.sub(r"\(.*", "", cur).replace("void ", "").replace("zlng::", "")
+            # k_rolz_parse_wg's sixth argument (kRingRule, round 6) defaults to false: such an instantiation IS the five-argument kernel of before
+            cur = re.sub(r"^(k_rolz_parse_wg<\d+(?:, (?:true|false)){4}), false>$", r"\1>", cur)
             res[cur] = []
             continue
         if cur is None:
@@ -42,6 +44,11 @@ def kernels(csrc, name):
             continue
         if not s or s.startswith((".loc", ".file", ".cfi", ".p2align", ".size", ".type", ".section", ".text", ".globl", ".protected", ".weak", ".hidden")):
             continue
+        s = re.sub(r"\.LBB\d+_", ".LBB_", s)         # block labels carry the function's index in the file: new instantiations shift it
+        if s.startswith((".Lfunc_begin", ".Ltmp")):
+            continue
+        if s.startswith(".amdhsa_kernel "):           # carries the mangled name (a defaulted template argument more changes it, not the code)
+            s = ".amdhsa_kernel"
         if s.startswith(".amdhsa_kernarg_size"):     # an argument appended BEHIND the ones a kernel reads changes this and nothing else
             continue
         res[cur].append(s)
