@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) CPU tests of the block-range sharding protocol over gloo.
+"""world_size-2, 3, 4 and 8 CPU tests of the block-range sharding protocol over gloo.
 
 The GPU stream object is replaced by a fake with the same interface whose codec is the oracle, so
 this checks the host logic that bench.py / multi-GPU callers run: range planning, per-rank batching over
@@ -124,7 +124,7 @@ def _worker(rank, world, port, total, tmp, kind, level, ctx_blocks, hybrid=False
 
     segs, lv_out = sharding.run_handoff(enc, rank, world, dist, buf, parse, finish, load_state, store_state, init_level)
     assert order[0] == "parse" and order[-1] == "finish"
-    z = np.concatenate([out[o:o + k] for o, k in segs])
+    z = np.concatenate([out[o:o + k] for o, k in segs]) if segs else np.empty(0, np.uint8)      # (a rank behind the end of a short stream has no range)
     z.tofile(os.path.join(tmp, "part%d.zlng" % rank))
     with open(os.path.join(tmp, "level%d.txt" % rank), "w") as f:
         f.write("%d %d" % (entry.get("level", -1), lv_out))
@@ -138,6 +138,9 @@ def _worker(rank, world, port, total, tmp, kind, level, ctx_blocks, hybrid=False
     (2, 2 * BLOCK + 300_000, "mixed", 4, 240),          # rank 0's range ends incompressible: rank 1 must enter at level 0
     (2, 4 * BLOCK + 50_000, "text", 0, 1),              # per-rank batching: 2-3 contexts of one block per rank
     (2, 4 * BLOCK + 50_001, "text", 0, 1),              # the same with the host-rank-chain switch set on every context (odd size = hybrid)
+    (4, 4 * BLOCK - 9, "mixed", 4, 240),                # BASELINE's 4- and 8-GPU shapes: the state crosses 3 / 7 hand-offs, at e4 the level with it
+    (4, 4 * BLOCK + 222_222, "text", 0, 240),           # five blocks over four ranks = 2 + 2 + 1 + 0: the last rank's range is EMPTY and only passes the state on
+    (8, 8 * BLOCK - 7, "text", 0, 240),                 # (rank 2 of 4 enters at level 0: the incompressible stretch ends rank 1's range)
 ])
 def test_block_range_sharding_equals_single_stream(tmp_path, world, total, kind, level, ctx_blocks):
     port = 29500 + (os.getpid() % 2000) + world + 7 * level + ctx_blocks % 5 + total % 3
@@ -147,8 +150,12 @@ def test_block_range_sharding_equals_single_stream(tmp_path, world, total, kind,
     parts = np.concatenate([np.fromfile(os.path.join(str(tmp_path), "part%d.zlng" % r), dtype=np.uint8) for r in range(world)])
     assert np.array_equal(parts, whole)
     if kind == "mixed":
-        entered, _ = (int(v) for v in open(os.path.join(str(tmp_path), "level1.txt")).read().split())
-        assert entered == 0, "rank 1 must receive current_level 0 from a range that ended incompressible"
+        edge = sharding.plan(total, 2)[1][0]                 # where make_input put the incompressible stretch: the range that starts there
+        r_in = next(r for r, (off, _n) in enumerate(sharding.plan(total, world)) if off == edge)
+        entered, _ = (int(v) for v in open(os.path.join(str(tmp_path), "level%d.txt" % r_in)).read().split())
+        assert entered == 0, "rank %d must receive current_level 0 from a range that ended incompressible" % r_in
+        if r_in > 1:                                         # ... and the ranks in front of it entered at the stream's level
+            assert int(open(os.path.join(str(tmp_path), "level1.txt")).read().split()[0]) == level
 
 
 def test_handoff_refuses_a_buffer_without_room_for_the_level():
