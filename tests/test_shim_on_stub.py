@@ -58,3 +58,51 @@ def test_the_shipped_shim_links_the_hip_library_not_the_stub():
     stub_syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "tests", "cxx", "_stub", "libzlng_hip.so")],
                                stdout=subprocess.PIPE, text=True).stdout
     assert "zlng_encode_blocks_device" not in stub_syms
+
+
+def test_group_driver_on_the_stub_failed_finish_leaves_the_state_and_the_range_can_be_resubmitted(stub, oracle):
+    """zlng_group.hip (the product's host code, compiled into the stand-in library) through ctypes: three members, a finish whose
+    output buffer is too small for the second member fails with ZLNG_E_CAP AFTER the first member's copy-out thread was started --
+    the driver joins it, reports the error, leaves the group's stream state as it was (zlng.h: "after a failed finish the group's
+    state is unchanged and the range has to be submitted again"), and the resubmitted range produces the single-stream bytes with
+    every block's end offset."""
+    import ctypes as C
+
+    import numpy as np
+    from oracle_py import textgen
+    L = C.CDLL(os.path.join(os.path.dirname(stub["zling_demo"]), "libzlng_hip.so"))
+    u8p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)
+    L.zlng_group_create.restype = C.c_void_p
+    L.zlng_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.zlng_group_destroy.argtypes = [C.c_void_p]
+    L.zlng_group_encode_parse.argtypes = [C.c_void_p, u8p, C.c_size_t]
+    L.zlng_group_encode_finish.argtypes = [C.c_void_p, u8p, C.c_size_t, szp, szp]
+    L.zlng_group_get_state.argtypes = [C.c_void_p, u8p, C.POINTER(C.c_int)]
+    L.zlng_encode_bound.restype = C.c_size_t
+    L.zlng_encode_bound.argtypes = [C.c_size_t]
+    BLOCK = 1 << 24
+    x = np.ascontiguousarray(textgen(3 * BLOCK - 1234, 17))
+    want = oracle.encode(x, 4)
+    devs = (C.c_int * 3)(0, 0, 0)
+    err = C.c_int(0)
+    g = L.zlng_group_create(devs, 3, 4, 1, C.byref(err))
+    assert g and err.value == 0
+    p = lambda a: a.ctypes.data_as(u8p)
+    st0, st1 = np.empty(65536, np.uint8), np.empty(65536, np.uint8)
+    lv = C.c_int(-1)
+    assert L.zlng_group_get_state(g, p(st0), C.byref(lv)) == 0 and lv.value == 4
+    out = np.empty(L.zlng_encode_bound(x.size), np.uint8)
+    n = C.c_size_t(0)
+    ends = (C.c_size_t * 3)()
+    assert L.zlng_group_encode_parse(g, p(x), x.size) == 0
+    small = want.size * 1 // 2                                           # room for member 0's block, not for member 1's
+    assert L.zlng_group_encode_finish(g, p(out), small, C.byref(n), ends) == -3      # ZLNG_E_CAP
+    assert n.value == 0
+    assert L.zlng_group_get_state(g, p(st1), C.byref(lv)) == 0 and lv.value == 4 and np.array_equal(st0, st1)
+    assert L.zlng_group_encode_finish(g, p(out), out.size, C.byref(n), ends) == -1    # nothing pending any more: ZLNG_E_ARG
+    assert L.zlng_group_encode_parse(g, p(x), x.size) == 0                             # submit the range again
+    assert L.zlng_group_encode_finish(g, p(out), out.size, C.byref(n), ends) == 0
+    assert n.value == want.size and np.array_equal(out[: n.value], want)
+    assert ends[2] == want.size and all(want[ends[b] - 1] == 0 for b in range(3))
+    assert L.zlng_group_get_state(g, p(st1), C.byref(lv)) == 0 and not np.array_equal(st0, st1)
+    L.zlng_group_destroy(g)
