@@ -10,6 +10,7 @@
 #   scripts/sanitize.sh host    on the GPU box: the C++ shim and zling_demo built with ASan + UBSan, the CLI tests through them
 #                               and the callback-protocol tests (tests/cxx/protocol_test.cpp) through them
 #                               (host side of the product path: Inputter/Outputter loops, batching, the helper thread, the exact-pull Decode)
+#   scripts/sanitize.sh host-tsan no GPU needed: the same host code under ThreadSanitizer on the stand-in ABI (helper thread of the shim's pipeline, copy-out threads of the group driver)
 #   scripts/sanitize.sh host-cpu  no GPU needed: the same host code (shim, group driver, zling_demo, protocol_test) under ASan + UBSan on the CPU
 #                               stand-in of the C-ABI (tests/cxx/zlng_stub.c, tests/stub_build.py --sanitize), the CLI / protocol / error-order tests through it
 # Logs go to gpurun_out/ (copy what should be kept into profiles/).
@@ -49,6 +50,13 @@ host)
   g++ -std=c++14 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I $ROOT/include/libzling -I $ROOT/include -o $B/protocol_test $ROOT/tests/cxx/protocol_test.cpp \
       -L $B -lzling_amd -L $ROOT/libzling_amd -lzlng_hip -Wl,-rpath,$B -Wl,-rpath,$ROOT/libzling_amd -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -pthread || exit 1
   ZLNG_DEMO=$B/zling_demo ZLNG_PROTOCOL_TEST=$B/protocol_test python -m pytest $ROOT/tests/test_gpu_cli.py $ROOT/tests/test_gpu_protocol.py -q -m gpu -p no:cacheprovider 2>&1 | tee $OUT/sanitize_host.log | tail -5
+  ;;
+host-tsan)
+  # ThreadSanitizer over the host threads of the product path: the shim's helper thread (two-slot pipeline) and the group driver's copy-out threads
+  python $ROOT/tests/stub_build.py --tsan || exit 1
+  B=$ROOT/tests/cxx/_stub_tsan
+  TSAN_OPTIONS=halt_on_error=1:exitcode=66 ZLNG_DEMO=$B/zling_demo ZLNG_PROTOCOL_TEST=$B/protocol_test python -m pytest $ROOT/tests/test_gpu_cli.py $ROOT/tests/test_gpu_protocol.py \
+      -q -m gpu -p no:cacheprovider -k "not python_stream and not split_host_api" 2>&1 | tee $OUT/sanitize_host_tsan.log | tail -5
   ;;
 host-cpu)
   python $ROOT/tests/stub_build.py --sanitize || exit 1

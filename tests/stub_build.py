@@ -20,10 +20,12 @@ def _stale(target, sources):
 
 
 def build(sanitize=False):
-    """sanitize=True: the same stack under ASan + UBSan in tests/cxx/_stub_asan/ (scripts/sanitize.sh host-cpu)."""
+    """sanitize=True: the same stack under ASan + UBSan in tests/cxx/_stub_asan/ (scripts/sanitize.sh host-cpu); sanitize="thread":
+    under ThreadSanitizer in tests/cxx/_stub_tsan/ (scripts/sanitize.sh host-tsan: the shim's helper thread, the group's copy-out threads)."""
     global OUT
-    OUT = os.path.join(ROOT, "tests", "cxx", "_stub_asan" if sanitize else "_stub")
-    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"] if sanitize else ["-O2"]
+    OUT = os.path.join(ROOT, "tests", "cxx", "_stub_tsan" if sanitize == "thread" else ("_stub_asan" if sanitize else "_stub"))
+    san = (["-fsanitize=thread", "-fno-omit-frame-pointer", "-g", "-O1"] if sanitize == "thread" else
+           ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"] if sanitize else ["-O2"])
     os.makedirs(OUT, exist_ok=True)
     hdrs = glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "include", "libzling", "*.h")) + \
         glob.glob(os.path.join(ROOT, "oracle", "*.h"))
@@ -55,4 +57,4 @@ def build(sanitize=False):
 
 if __name__ == "__main__":
     import sys
-    print(build(sanitize="--sanitize" in sys.argv))
+    print(build(sanitize="thread" if "--tsan" in sys.argv else ("--sanitize" in sys.argv)))
