@@ -15,6 +15,7 @@
  *                        inside a block come in stream order (the checker's decoder is the reference's one loop); a buffer that
  *                        is too small reports nothing and leaves the state (ZLNG_E_CAP)
  */
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -125,6 +126,27 @@ int zlng_encode_blocks(zlng_ctx* c, const uint8_t* in, size_t in_len, uint8_t* o
     return rc != ZLNG_OK ? rc : zlng_encode_finish(c, out, out_cap, out_len, ends);
 }
 
+/* The device-pointer forms.  There is no device here: in the stand-in a "device pointer" is a host address (the CPU tests hand numpy /
+ * torch-CPU buffers' addresses where the GPU tests hand tensor.data_ptr()), and the calls are their host-buffer twins.  They exist so
+ * that the Python view of the ABI (libzling_amd/__init__.py: Stream, Group) and sharding.RangeEncoder with REAL Stream objects can be
+ * driven on the CPU (tests/test_python_binding_on_stub.py); what they say about the kernels is nothing. */
+int zlng_stub_marker(void) { return 1; }                /* only the stand-in exports this */
+int zlng_encode_parse_device(zlng_ctx* c, const void* d_in, size_t in_len) { return zlng_encode_parse(c, (const uint8_t*)d_in, in_len); }
+int zlng_encode_finish_device(zlng_ctx* c, void* d_out, size_t out_cap, size_t* out_len, size_t* ends) {
+    if (((uintptr_t)d_out & 3) != 0) return ZLNG_E_ARG; /* zlng_api.hip: the output starts on a 4-byte boundary */
+    return zlng_encode_finish(c, (uint8_t*)d_out, out_cap, out_len, ends);
+}
+int zlng_encode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, void* d_out, size_t out_cap, size_t* out_len, size_t* ends) {
+    if (!c || !out_len) return ZLNG_E_ARG;
+    *out_len = 0;
+    if (in_len == 0) return ZLNG_OK;
+    const int rc = zlng_encode_parse_device(c, d_in, in_len);
+    return rc != ZLNG_OK ? rc : zlng_encode_finish_device(c, d_out, out_cap, out_len, ends);
+}
+int zlng_encode_parse_after(zlng_ctx* c, zlng_ctx* first) { return (!c || !first || !c->is_encode || !first->is_encode) ? ZLNG_E_ARG : ZLNG_OK; }
+int zlng_last_timings(zlng_ctx* c, const char** names, float* ms, int cap) { (void)c; (void)names; (void)ms; (void)cap; return 0; }
+void* zlng_stream(zlng_ctx* c) { (void)c; return NULL; }
+
 int zlng_set_host_rank_contexts(zlng_ctx* c, int k) { return (!c || !c->is_encode || k < 0) ? ZLNG_E_ARG : ZLNG_OK; }   /* same bytes by definition */
 
 int zlng_get_state(zlng_ctx* c, uint8_t mtf[ZLNG_MTF_STATE], int* current_level) {
@@ -144,6 +166,9 @@ int zlng_set_state(zlng_ctx* c, const uint8_t mtf[ZLNG_MTF_STATE], int current_l
     else zo_dstream_set_mtf(c->ds, mtf);
     return ZLNG_OK;
 }
+
+int zlng_get_state_device(zlng_ctx* c, void* d_mtf, int* current_level) { return zlng_get_state(c, (uint8_t*)d_mtf, current_level); }
+int zlng_set_state_device(zlng_ctx* c, const void* d_mtf, int current_level) { return zlng_set_state(c, (const uint8_t*)d_mtf, current_level); }
 
 static int map_err(int zo) {
     switch (zo) {
@@ -195,6 +220,11 @@ int zlng_decode_blocks(zlng_ctx* c, const uint8_t* in, size_t in_len, size_t* in
     if (rc != ZLNG_OK) return rc;
     *out_len = op;
     return ZLNG_OK;
+}
+
+int zlng_decode_blocks_device(zlng_ctx* c, const void* d_in, size_t in_len, size_t* in_used, void* d_out, size_t out_cap,
+                              size_t* out_len, size_t* per_block_out_end) {
+    return zlng_decode_blocks(c, (const uint8_t*)d_in, in_len, in_used, (uint8_t*)d_out, out_cap, out_len, per_block_out_end);
 }
 
 const char* zlng_strerror(int code) {                    /* the product's table (zlng_api.hip); the decode messages are the reference's */

@@ -54,10 +54,13 @@ def test_the_shipped_shim_links_the_hip_library_not_the_stub():
     out = subprocess.run(["readelf", "-d", build.SHIM_SO], stdout=subprocess.PIPE, text=True, check=True).stdout
     assert "libzlng_hip.so" in out and "$ORIGIN" in out
     syms = subprocess.run(["nm", "-D", "--defined-only", build.HIP_SO], stdout=subprocess.PIPE, text=True, check=True).stdout
-    assert "zlng_encode_blocks_device" in syms and "zlng_decode_blocks_device" in syms
-    stub_syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "tests", "cxx", "_stub", "libzlng_hip.so")],
-                               stdout=subprocess.PIPE, text=True).stdout
-    assert "zlng_encode_blocks_device" not in stub_syms
+    assert "zlng_encode_blocks_device" in syms and "zlng_debug_fetch" in syms and "zlng_stub_marker" not in syms
+    needed = subprocess.run(["readelf", "-d", build.HIP_SO], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "libamdhip64" in needed                                       # the shipped library is the HIP build
+    stub_so = os.path.join(ROOT, "tests", "cxx", "_stub", "libzlng_hip.so")
+    stub_syms = subprocess.run(["nm", "-D", "--defined-only", stub_so], stdout=subprocess.PIPE, text=True).stdout
+    assert "zlng_stub_marker" in stub_syms and "zlng_debug_fetch" not in stub_syms
+    assert "libamdhip64" not in subprocess.run(["readelf", "-d", stub_so], stdout=subprocess.PIPE, text=True).stdout
 
 
 def test_group_driver_on_the_stub_failed_finish_leaves_the_state_and_the_range_can_be_resubmitted(stub, oracle):
