@@ -47,6 +47,19 @@ from libzling_amd import sharding
 from libzling_amd.textgen import textgen
 
 BLOCK = zl.BLOCK
+# TEST HOOK, never a benchmark: ZLNG_BENCH_STANDIN=1 together with ZLNG_HIP_SO=<tests/cxx/_stub/libzlng_hip.so> runs this file's HOST logic
+# -- ranges, hand-off, timing brackets, the parity column, every extra, the JSON line -- on the CPU against the stand-in of the C-ABI that the
+# CPU suite builds on the checker (tests/cxx/zlng_stub.c; a "device pointer" is a host address there).  tests/test_bench_on_stub.py uses it
+# so that a line of this file that never met a GPU has at least been executed.  Without BOTH variables nothing here runs without a gfx950 device.
+STANDIN = os.environ.get("ZLNG_BENCH_STANDIN") == "1"
+DEV = "cpu" if STANDIN else "cuda"
+
+
+def sync():
+    if DEV == "cuda":
+        torch.cuda.synchronize()
+
+
 METRIC = "encode MB/s (input) at e0 on enwik9; bit-exact .zlng; 1/2/4/8 GPU"
 METRIC_DECODE = "decode MB/s (output) of the e0 enwik9 .zlng; bit-exact round trip; 1 GPU"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -235,7 +248,7 @@ def gpu_multistream(k, x, level, local, want_sha, alone_ms, device=None):
     n = int(x.size)
     nb = (n + BLOCK - 1) // BLOCK
     cap = zl.encode_bound(n)
-    dev = device or torch.device("cuda", local)                  # (device: tests/test_bench_host.py drives the host logic on the CPU)
+    dev = device or (torch.device("cpu") if STANDIN else torch.device("cuda", local))     # (device: tests/test_bench_host.py drives the host logic on the CPU)
     hx = torch.from_numpy(x)
     d_in, d_out, ctx = [], [], []
     try:
@@ -351,7 +364,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpu_multistream_child:                                   # the isolated leg of gpu_multistream (see gpu_multistream_isolated)
-        torch.cuda.set_device(args.child_device)
+        if not STANDIN:
+            torch.cuda.set_device(args.child_device)
         x, source = load_input(args.size, 0)
         print(json.dumps(gpu_multistream(args.gpu_multistream_child, x, args.level, args.child_device,
                                          None if args.child_want_sha == "-" else args.child_want_sha, args.child_alone_ms)))
@@ -368,7 +382,13 @@ def main():
     one_dev = os.environ.get("ZLNG_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local = 0
-    torch.cuda.set_device(local)
+    if STANDIN:
+        if zl.lib().zlng_device_count() < 1 or not hasattr(zl.lib(), "zlng_stub_marker"):
+            sys.exit("ZLNG_BENCH_STANDIN=1 is a test hook for the stand-in ABI (ZLNG_HIP_SO=tests/cxx/_stub/libzlng_hip.so); it refuses the real library")
+        one_dev = True                                               # collectives over gloo, every rank on "device" 0
+        local = 0
+    else:
+        torch.cuda.set_device(local)
     cdev = "cpu" if one_dev else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -391,7 +411,7 @@ def main():
         ranges = [(0, n)]
     x, source = load_input(n, first_chunk)
     nb = (n + BLOCK - 1) // BLOCK
-    d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
+    d_in = torch.empty(n + 512, dtype=torch.uint8, device=DEV)
     d_in[:n].copy_(torch.from_numpy(x))
     d_in[n:].zero_()
     enc = sharding.RangeEncoder(lambda blocks: zl.Stream(local, args.level, True, blocks), nb, min(240, args.ctx_blocks), args.parses_in_flight,
@@ -399,10 +419,10 @@ def main():
                                 parts=[int(v) for v in args.parts.split(",")] if args.parts else None)
     stag_used = [enc.stagger_plan() if enc.stagger else None]      # (first, gap_s) of the LAST step (auto: re-derived from every step's rank stages)
     cap = zl.encode_bound(n) + 4 * len(enc.parts)
-    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    d_state = torch.empty(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(cap, dtype=torch.uint8, device=DEV)
+    d_state = torch.empty(sharding.STATE_BUF, dtype=torch.uint8, device=DEV)
     init_state, init_level = enc.streams[0].get_state()
-    d_state0 = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8, device="cuda")
+    d_state0 = torch.zeros(sharding.STATE_BUF, dtype=torch.uint8, device=DEV)
     d_state0[:zl.MTF_STATE].copy_(torch.from_numpy(init_state))
     h_state = torch.empty(sharding.STATE_BUF, dtype=torch.uint8) if one_dev else None
 
@@ -412,7 +432,7 @@ def main():
     def load_state(buf):                                             # received buffer -> this rank's entry state
         if one_dev:
             d_state.copy_(buf)
-        torch.cuda.synchronize()                                     # the receive / copy ran on torch's streams
+        sync()                                     # the receive / copy ran on torch's streams
         return int(buf[zl.MTF_STATE].item())
 
     def store_state(buf, level):                                     # exit state (already in d_state) -> buffer to send
@@ -425,18 +445,18 @@ def main():
             stag_used[0] = enc.stagger_plan()
         if single:
             if rank == 0:
-                d_state.copy_(d_state0); torch.cuda.synchronize()
+                d_state.copy_(d_state0); sync()
             return sharding.run_handoff(enc, rank, world, dist, h_state if one_dev else d_state,
                                         parse=lambda: enc.parse(d_in.data_ptr(), n), finish=finish,
                                         load_state=load_state, store_state=store_state, initial_level=init_level)
-        d_state.copy_(d_state0); torch.cuda.synchronize()           # a fresh stream every step
+        d_state.copy_(d_state0); sync()           # a fresh stream every step
         enc.parse(d_in.data_ptr(), n)
         return finish(init_level)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     segs = []
     for _ in range(args.warmup):
@@ -622,10 +642,10 @@ def realtext_workload(args, local):
     if n < (64 << 20):
         return {"value_realtext": None, "realtext_note": "only %d bytes of text files in this image" % n}
     nb = (n + BLOCK - 1) // BLOCK
-    d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda")
+    d_in = torch.empty(n + 512, dtype=torch.uint8, device=DEV)
     d_in[:n].copy_(torch.from_numpy(x)); d_in[n:].zero_()
     cap = zl.encode_bound(n)
-    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(cap, dtype=torch.uint8, device=DEV)
     with zl.Stream(local, args.level, True, nb) as s:
         st0, lv0 = s.get_state()
 
@@ -634,11 +654,11 @@ def realtext_workload(args, local):
             return s.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
         for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             m = step()
-        torch.cuda.synchronize()
+        sync()
         dt = (time.perf_counter() - t0) / args.steps
         stage = dict(s.timings())
         hot = s.debug_fetch(8, 0, np.uint32, 256)
@@ -667,15 +687,15 @@ def alt_host_rank(args, local, nb, d_in, n, d_out, cap, d_state, d_state0, init_
             s.set_host_rank_contexts(4)
 
             def step():
-                d_state.copy_(d_state0); torch.cuda.synchronize()
+                d_state.copy_(d_state0); sync()
                 s.set_state_device(d_state.data_ptr(), init_level)
                 return s.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
             step()
-            torch.cuda.synchronize()
+            sync()
             t0 = time.perf_counter()
             for _ in range(2):
                 m = step()
-            torch.cuda.synchronize()
+            sync()
             dt = (time.perf_counter() - t0) / 2
             st = dict(s.timings())
             same = bool(m == want.size and np.array_equal(d_out[:m].cpu().numpy(), want))
@@ -695,9 +715,9 @@ def bench_decode(args, world, rank, local):
     with zl.Stream(local, args.level, True, nb) as s:
         z = s.encode(x)
         ends = list(s.block_ends)
-    d_z = torch.empty(z.size + 512, dtype=torch.uint8, device="cuda")
+    d_z = torch.empty(z.size + 512, dtype=torch.uint8, device=DEV)
     d_z[: z.size].copy_(torch.from_numpy(z)); d_z[z.size:].zero_()
-    d_raw = torch.empty(nb * BLOCK + 512, dtype=torch.uint8, device="cuda")
+    d_raw = torch.empty(nb * BLOCK + 512, dtype=torch.uint8, device=DEV)
     dec = zl.Stream(local, 0, False, nb)
     init_state, init_level = dec.get_state()
 
@@ -707,11 +727,11 @@ def bench_decode(args, world, rank, local):
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         used, produced = step()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     stage = dict(dec.timings())
     dom = max(stage, key=stage.get)
