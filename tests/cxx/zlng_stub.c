@@ -32,6 +32,8 @@ struct zlng_ctx {
     size_t pending_len;
     uint8_t* staged;                                     /* zlng_encode_finish_staged -> zlng_encode_copy_out */
     size_t staged_len;
+    uint8_t* last_in;                                    /* the range of the last finished encode call (zlng_debug_fetch) */
+    size_t last_len;
     double last_ms;                                      /* wall time of the last finish / decode call (zlng_last_timings) */
 };
 
@@ -59,6 +61,7 @@ void zlng_destroy(zlng_ctx* c) {
     if (c->ds) zo_dstream_free(c->ds);
     free(c->pending);
     free(c->staged);
+    free(c->last_in);
     free(c);
 }
 
@@ -101,8 +104,36 @@ int zlng_encode_finish(zlng_ctx* c, uint8_t* out, size_t out_cap, size_t* out_le
             p += 13 + ((size_t)out[p + 9] << 24 | (size_t)out[p + 10] << 16 | (size_t)out[p + 11] << 8 | out[p + 12]);
         }
     }
-    free(c->pending); c->pending = NULL; c->pending_len = 0;
+    free(c->last_in); c->last_in = c->pending; c->last_len = c->pending_len;      /* kept for zlng_debug_fetch(8) */
+    c->pending = NULL; c->pending_len = 0;
     *out_len = n;
+    return ZLNG_OK;
+}
+
+/* Test hook, `what` = 8 only (literals per context of the last encode call: what bench.py's rank_chain line asks for): the range is
+ * parsed again with the checker's stage API and the literal tokens counted by their context byte.  The other hooks look into the
+ * kernels' buffers and have no counterpart here. */
+int zlng_debug_fetch(zlng_ctx* c, int what, int blk, void* dst, size_t bytes) {
+    (void)blk;
+    if (!c || !c->is_encode || what != 8 || !dst || bytes > 256 * 4 || !c->last_in) return ZLNG_E_ARG;
+    uint32_t cnt[256] = {0};
+    zo_stream* s = zo_stream_new(c->level);
+    uint32_t* tok = (uint32_t*)malloc(sizeof(uint32_t) * ZO_SUBBLOCK_SYMS);
+    uint8_t* ibuf = (uint8_t*)malloc(ZO_BLOCK_IN + ZO_SENTINEL);
+    if (!s || !tok || !ibuf) { free(tok); free(ibuf); if (s) zo_stream_free(s); return ZLNG_E_NOMEM; }
+    for (size_t base = 0; base < c->last_len; base += ZO_BLOCK_IN) {
+        const int ilen = (int)(c->last_len - base < ZO_BLOCK_IN ? c->last_len - base : ZO_BLOCK_IN);
+        memcpy(ibuf, c->last_in + base, (size_t)ilen);
+        memset(ibuf + ilen, 0, ZO_SENTINEL);
+        zo_reset_buckets(s);
+        int encpos = 0, rlen = 0;
+        while (encpos < ilen) {
+            const int nt = zo_parse_subblock(s, c->level, ibuf, ilen, &encpos, tok, &rlen, 0);
+            for (int i = 0; i < nt; i++) { const uint32_t sym = tok[i] & 0xFFFF, aux = tok[i] >> 16; if (sym < 256 && aux < 256) cnt[aux]++; }
+        }
+    }
+    free(tok); free(ibuf); zo_stream_free(s);
+    memcpy(dst, cnt, bytes);
     return ZLNG_OK;
 }
 

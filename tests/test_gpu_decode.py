@@ -145,7 +145,7 @@ def test_cli_decodes_an_unterminated_final_block(tmp_path, oracle):
     terminator is still written.  Through the C++ API (tools/zling_demo)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    demo = os.path.join(root, "tools", "zling_demo")
+    demo = os.environ.get("ZLNG_DEMO") or os.path.join(root, "tools", "zling_demo")
     x = corpus.get("text_64k")
     z = oracle.encode(x, 0)
     assert z[-1] == 0

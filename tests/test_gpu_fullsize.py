@@ -75,7 +75,7 @@ def test_enwik8_shape_e0_serial_blocks_and_cli(tmp_path, manifest, capsys):
         print("\n[config 2] 100,000,000 B at e0, one 16 MiB block in flight, host to host: %.2f s = %.1f MB/s" % (dt, n / dt / 1e6))
     src, enc, dec = str(tmp_path / "enwik8.shape"), str(tmp_path / "o.zlng"), str(tmp_path / "o.bin")
     x.tofile(src)
-    demo = os.path.join(ROOT, "tools", "zling_demo")
+    demo = os.environ.get("ZLNG_DEMO") or os.path.join(ROOT, "tools", "zling_demo")
     t0 = time.perf_counter(); subprocess.check_call([demo, "e0", src, enc], stderr=subprocess.DEVNULL); te = time.perf_counter() - t0
     zc = np.fromfile(enc, dtype=np.uint8)
     assert zc.size == pin["zlng_bytes"] and hashlib.sha256(zc.tobytes()).hexdigest() == pin["sha256"]

@@ -36,6 +36,16 @@ def test_cli_tests_of_the_gpu_suite_hold_the_shim_on_the_stub(stub):
     assert " passed" in tail and "failed" not in tail
 
 
+def test_unterminated_final_block_through_the_cli_on_the_stub(stub):
+    for ra in ("0", "1"):                                                # both Decode paths of the shim
+        os.environ["ZLNG_DECODE_READAHEAD"] = ra
+        try:
+            tail = run_gpu_tests_on_stub(stub, ["test_gpu_decode.py"], "unterminated_final_block")
+        finally:
+            del os.environ["ZLNG_DECODE_READAHEAD"]
+        assert "1 passed" in tail
+
+
 def test_protocol_tests_of_the_gpu_suite_hold_the_shim_on_the_stub(stub):
     tail = run_gpu_tests_on_stub(stub, ["test_gpu_protocol.py"])
     assert " passed" in tail and "failed" not in tail
@@ -54,12 +64,12 @@ def test_the_shipped_shim_links_the_hip_library_not_the_stub():
     out = subprocess.run(["readelf", "-d", build.SHIM_SO], stdout=subprocess.PIPE, text=True, check=True).stdout
     assert "libzlng_hip.so" in out and "$ORIGIN" in out
     syms = subprocess.run(["nm", "-D", "--defined-only", build.HIP_SO], stdout=subprocess.PIPE, text=True, check=True).stdout
-    assert "zlng_encode_blocks_device" in syms and "zlng_debug_fetch" in syms and "zlng_stub_marker" not in syms
+    assert "zlng_encode_blocks_device" in syms and "zlng_debug_lengths" in syms and "zlng_stub_marker" not in syms
     needed = subprocess.run(["readelf", "-d", build.HIP_SO], stdout=subprocess.PIPE, text=True, check=True).stdout
     assert "libamdhip64" in needed                                       # the shipped library is the HIP build
     stub_so = os.path.join(ROOT, "tests", "cxx", "_stub", "libzlng_hip.so")
     stub_syms = subprocess.run(["nm", "-D", "--defined-only", stub_so], stdout=subprocess.PIPE, text=True).stdout
-    assert "zlng_stub_marker" in stub_syms and "zlng_debug_fetch" not in stub_syms
+    assert "zlng_stub_marker" in stub_syms and "zlng_debug_lengths" not in stub_syms
     assert "libamdhip64" not in subprocess.run(["readelf", "-d", stub_so], stdout=subprocess.PIPE, text=True).stdout
 
 
