@@ -194,7 +194,8 @@ int zlng_last_timings(zlng_ctx*, const char** names, float* ms, int cap);
  *  default; a process that drives a range through several contexts at once should give every stream its own queue, as bench.py does.)
  * (The C++ shim reads ZLNG_DEVICE, ZLNG_DEVICES, ZLNG_BATCH_BLOCKS and ZLNG_PIPELINE: INTEGRATION.md.  The build reads
  *  ZLNG_HIPCC_FLAGS and ZLNG_BUILD_FORCE (__graft_entry__.py); bench.py reads ZLNG_ENWIK9 / ZLNG_ENWIK8 (a real enwik file
- *  to use instead of the generator) and ZLNG_BENCH_ONE_DEVICE (all ranks on device 0, collectives over gloo: a test hook);
+ *  to use instead of the generator) and ZLNG_BENCH_ONE_DEVICE (all ranks on device 0, collectives over gloo: a test hook), ZLNG_BENCH_STANDIN (with ZLNG_HIP_SO naming
+ *  the CPU stand-in of this ABI that the test suite builds, tests/cxx/zlng_stub.c: bench.py's host logic on the CPU -- a test hook, never a measurement);
  *  scripts/sanitize.sh sets ZLNG_ORACLE_SO (the ASan build of the oracle), ZLNG_NO_REF, ZLNG_DEMO, ZLNG_PROTOCOL_TEST, ZLNG_HIP_SO (another build of libzlng_hip.so) and ZLNG_SYSTEM_HIP (the ASan build of zling_demo) for the tests.) */
 
 /* Test hooks (used by tests/ and scripts/ only; no stability promise):
