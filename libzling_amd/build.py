@@ -99,11 +99,14 @@ def build_protocol_test(force=False):
 
 
 def build_all(force=False, verbose=False):
-    build_textgen(force)
-    build_hip(force, verbose)
-    build_shim(force)
-    build_demo(force)
-    build_protocol_test(force)
+    import fcntl
+    with open(os.path.join(PKG, ".build.lock"), "w") as lock:       # one builder at a time (parallel test workers all ask for an up-to-date tree)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        build_textgen(force)
+        build_hip(force, verbose)
+        build_shim(force)
+        build_demo(force)
+        build_protocol_test(force)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,10 @@ def build(force=False):
     src = os.path.join(HERE, "zlng_oracle.c")
     stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
     if force or stale or (os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(HERE, "_ref", "libzling_ref.so"))):
-        subprocess.check_call(["make", "-s", "-C", HERE])
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lock:      # parallel test workers: one make at a time
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", HERE])
     return so
 
 

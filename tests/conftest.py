@@ -9,6 +9,16 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`) spreads over four workers when pytest-xdist is there and no -n was given: its tests are
+    independent processes' worth of work (checker differentials, the stand-in stacks, gloo worlds) and take ~9 minutes in a row,
+    ~3 side by side.  Never for the GPU suite (one device), never when a worker count was asked for; ZLNG_TESTS_SERIAL=1 opts out."""
+    if (getattr(config.option, "markexpr", "") == "not gpu" and hasattr(config.option, "numprocesses") and not config.option.numprocesses
+            and not os.environ.get("ZLNG_TESTS_SERIAL") and not getattr(config.option, "collectonly", False)):
+        config.option.numprocesses = min(4, os.cpu_count() or 1)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

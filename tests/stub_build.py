@@ -27,6 +27,17 @@ def build(sanitize=False):
     san = (["-fsanitize=thread", "-fno-omit-frame-pointer", "-g", "-O1"] if sanitize == "thread" else
            ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"] if sanitize else ["-O2"])
     os.makedirs(OUT, exist_ok=True)
+    import fcntl
+    lock = open(os.path.join(OUT, ".lock"), "w")                      # several test workers may ask for the stack at once
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _build(OUT, san)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build(OUT, san):
     hdrs = glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "include", "libzling", "*.h")) + \
         glob.glob(os.path.join(ROOT, "oracle", "*.h"))
     abi = os.path.join(OUT, "libzlng_hip.so")
